@@ -1,0 +1,350 @@
+// capi.hip -- the extern "C" surface of libdsp_gpu.so (declared in include/dsp_gpu.h).
+//
+// Validates arguments, stages host buffers when mem == DSP_GPU_MEM_HOST, keeps the
+// per-device workspaces and the cache of uploaded tap sets, and forwards to the kernel
+// launchers.  Nothing here computes samples on the CPU: if HIP is unusable the calls
+// fail with DSP_GPU_EHIP.
+#include <cmath>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+#include "common.h"
+
+namespace dspgpu {
+
+char *last_error_buffer() {
+    static thread_local char buf[kLastErrorBytes] = "";
+    return buf;
+}
+
+namespace {
+
+constexpr int kMaxDevices = 64;
+
+struct Buffer {
+    void *ptr = nullptr;
+    size_t bytes = 0;
+};
+
+struct TapEntry {  // uploaded tap set (+ lazily built overlap-save spectrum)
+    std::vector<float> taps;
+    float *d_taps = nullptr;
+    float2 *d_spectrum = nullptr;  // 4096-point spectrum of the zero-padded taps
+};
+
+struct DeviceState {
+    Buffer ws[WS_SLOTS];
+    std::vector<TapEntry> taps;
+};
+
+std::mutex g_mutex;
+DeviceState g_dev[kMaxDevices];
+
+int current_device(int *dev) {
+    DSPGPU_HIP(hipGetDevice(dev));
+    if (*dev < 0 || *dev >= kMaxDevices) return fail(DSP_GPU_EUNSUPPORTED, "device index %d out of range", *dev);
+    return DSP_GPU_OK;
+}
+
+// Find or upload a tap set on the current device.  Sets are tiny (<= 16 KiB) and few.
+int cached_taps(const float *taps, int ntaps, bool want_spectrum, hipStream_t s, TapEntry **out) {
+    int dev = 0;
+    if (int rc = current_device(&dev)) return rc;
+    std::lock_guard<std::mutex> lock(g_mutex);
+    DeviceState &st = g_dev[dev];
+    TapEntry *hit = nullptr;
+    for (TapEntry &e : st.taps)
+        if (static_cast<int>(e.taps.size()) == ntaps && std::memcmp(e.taps.data(), taps, sizeof(float) * ntaps) == 0) {
+            hit = &e;
+            break;
+        }
+    if (!hit) {
+        if (st.taps.size() >= 64) {  // bounded cache: drop everything when full
+            DSPGPU_HIP(hipDeviceSynchronize());
+            for (TapEntry &e : st.taps) {
+                if (e.d_taps) (void)hipFree(e.d_taps);
+                if (e.d_spectrum) (void)hipFree(e.d_spectrum);
+            }
+            st.taps.clear();
+        }
+        TapEntry e;
+        e.taps.assign(taps, taps + ntaps);
+        if (hipMalloc(&e.d_taps, sizeof(float) * ntaps) != hipSuccess)
+            return fail(DSP_GPU_ENOMEM, "hipMalloc of %d taps failed", ntaps);
+        // synchronous copy from pageable host memory: done once per tap set
+        hipError_t ce = hipMemcpy(e.d_taps, taps, sizeof(float) * ntaps, hipMemcpyHostToDevice);
+        if (ce != hipSuccess) {
+            (void)hipFree(e.d_taps);
+            return fail(DSP_GPU_EHIP, "tap upload failed: %s", hipGetErrorString(ce));
+        }
+        st.taps.reserve(64);
+        st.taps.push_back(std::move(e));
+        hit = &st.taps.back();
+    }
+    if (want_spectrum && !hit->d_spectrum) {
+        if (hipMalloc(&hit->d_spectrum, sizeof(float2) * 4096) != hipSuccess)
+            return fail(DSP_GPU_ENOMEM, "hipMalloc of the tap spectrum failed");
+        if (int rc = launch_fir_spectrum(hit->d_taps, ntaps, hit->d_spectrum, s)) return rc;
+        // the spectrum is built on `s`; later users on other streams must see it complete
+        DSPGPU_HIP(hipStreamSynchronize(s));
+    }
+    *out = hit;
+    return DSP_GPU_OK;
+}
+
+struct HostStage {  // mem == HOST helper: device mirrors of the caller's buffers
+    void *d_in = nullptr;
+    void *d_out = nullptr;
+};
+
+int stage_in(const void *host, size_t in_bytes, size_t out_bytes, hipStream_t s, HostStage *hs) {
+    if (int rc = workspace(WS_STAGE_IN, in_bytes, &hs->d_in)) return rc;
+    if (int rc = workspace(WS_STAGE_OUT, out_bytes, &hs->d_out)) return rc;
+    DSPGPU_HIP(hipMemcpyAsync(hs->d_in, host, in_bytes, hipMemcpyHostToDevice, s));
+    return DSP_GPU_OK;
+}
+
+int stage_out(void *host, size_t out_bytes, hipStream_t s, const HostStage &hs) {
+    DSPGPU_HIP(hipMemcpyAsync(host, hs.d_out, out_bytes, hipMemcpyDeviceToHost, s));
+    DSPGPU_HIP(hipStreamSynchronize(s));
+    return DSP_GPU_OK;
+}
+
+bool bad_mem(int mem) { return mem != DSP_GPU_MEM_HOST && mem != DSP_GPU_MEM_DEVICE; }
+
+}  // namespace
+
+int workspace(WorkspaceSlot slot, size_t bytes, void **ptr) {
+    int dev = 0;
+    if (int rc = current_device(&dev)) return rc;
+    std::lock_guard<std::mutex> lock(g_mutex);
+    Buffer &b = g_dev[dev].ws[slot];
+    if (b.bytes < bytes) {
+        if (b.ptr) {
+            DSPGPU_HIP(hipDeviceSynchronize());  // earlier launches may still use the old buffer
+            (void)hipFree(b.ptr);
+            b.ptr = nullptr;
+            b.bytes = 0;
+        }
+        const size_t want = (bytes + 255) & ~static_cast<size_t>(255);
+        if (hipMalloc(&b.ptr, want) != hipSuccess) {
+            b.ptr = nullptr;
+            return fail(DSP_GPU_ENOMEM, "workspace allocation of %zu bytes failed", want);
+        }
+        b.bytes = want;
+    }
+    *ptr = b.ptr;
+    return DSP_GPU_OK;
+}
+
+void release_all_workspaces() {
+    std::lock_guard<std::mutex> lock(g_mutex);
+    int saved = 0, count = 0;
+    if (hipGetDevice(&saved) != hipSuccess || hipGetDeviceCount(&count) != hipSuccess) return;
+    for (int d = 0; d < count && d < kMaxDevices; ++d) {
+        DeviceState &st = g_dev[d];
+        bool used = !st.taps.empty();
+        for (const Buffer &b : st.ws) used = used || b.ptr;
+        if (!used) continue;
+        if (hipSetDevice(d) != hipSuccess) continue;
+        (void)hipDeviceSynchronize();
+        for (Buffer &b : st.ws) {
+            if (b.ptr) (void)hipFree(b.ptr);
+            b = Buffer{};
+        }
+        for (TapEntry &e : st.taps) {
+            if (e.d_taps) (void)hipFree(e.d_taps);
+            if (e.d_spectrum) (void)hipFree(e.d_spectrum);
+        }
+        st.taps.clear();
+    }
+    (void)hipSetDevice(saved);
+}
+
+}  // namespace dspgpu
+
+using namespace dspgpu;
+
+extern "C" {
+
+int dsp_gpu_fft_batch(const void *in, void *out, int log2n, size_t batch, int direction, int mem, void *stream) {
+    if (!in || !out) return fail(DSP_GPU_EINVAL, "dsp_gpu_fft_batch: null buffer");
+    if (log2n < 1 || log2n > 24) return fail(DSP_GPU_EINVAL, "dsp_gpu_fft_batch: log2n %d outside [1,24]", log2n);
+    if (direction != DSP_GPU_FORWARD && direction != DSP_GPU_INVERSE)
+        return fail(DSP_GPU_EINVAL, "dsp_gpu_fft_batch: direction %d", direction);
+    if (bad_mem(mem)) return fail(DSP_GPU_EINVAL, "dsp_gpu_fft_batch: mem %d", mem);
+    if (batch == 0) return DSP_GPU_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t bytes = (batch << log2n) * sizeof(float2);
+    if (mem == DSP_GPU_MEM_DEVICE)
+        return launch_fft_batch(static_cast<const float2 *>(in), static_cast<float2 *>(out), log2n, batch, direction, s);
+    HostStage hs;
+    if (int rc = stage_in(in, bytes, bytes, s, &hs)) return rc;
+    if (int rc = launch_fft_batch(static_cast<const float2 *>(hs.d_in), static_cast<float2 *>(hs.d_out), log2n, batch,
+                                  direction, s))
+        return rc;
+    return stage_out(out, bytes, s, hs);
+}
+
+int dsp_gpu_fft_batch_timed(const void *in, void *out, int log2n, size_t batch, int direction, int iters,
+                            float *ms_per_launch, void *stream) {
+    if (!in || !out || !ms_per_launch || iters < 1) return fail(DSP_GPU_EINVAL, "dsp_gpu_fft_batch_timed: bad argument");
+    if (log2n < 1 || log2n > 24) return fail(DSP_GPU_EINVAL, "dsp_gpu_fft_batch_timed: log2n %d", log2n);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipEvent_t e0, e1;
+    DSPGPU_HIP(hipEventCreate(&e0));
+    DSPGPU_HIP(hipEventCreate(&e1));
+    int rc = DSP_GPU_OK;
+    hipError_t he = hipEventRecord(e0, s);
+    for (int i = 0; i < iters && rc == DSP_GPU_OK; ++i)
+        rc = launch_fft_batch(static_cast<const float2 *>(in), static_cast<float2 *>(out), log2n, batch, direction, s);
+    if (he == hipSuccess) he = hipEventRecord(e1, s);
+    if (he == hipSuccess) he = hipEventSynchronize(e1);
+    float ms = 0.0f;
+    if (he == hipSuccess) he = hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (rc != DSP_GPU_OK) return rc;
+    if (he != hipSuccess) return fail(DSP_GPU_EHIP, "event timing failed: %s", hipGetErrorString(he));
+    *ms_per_launch = ms / static_cast<float>(iters);
+    return DSP_GPU_OK;
+}
+
+int dsp_gpu_fft_real_batch(const float *in, size_t n_in, size_t in_stride, void *out, int nf, size_t batch,
+                           int direction, int shifted, int mem, void *stream) {
+    if (!in || !out) return fail(DSP_GPU_EINVAL, "dsp_gpu_fft_real_batch: null buffer");
+    if (nf < 2) return fail(DSP_GPU_EINVAL, "dsp_gpu_fft_real_batch: nf %d < 2", nf);
+    if (in_stride < n_in) return fail(DSP_GPU_EINVAL, "dsp_gpu_fft_real_batch: in_stride < n_in");
+    if (direction != DSP_GPU_FORWARD && direction != DSP_GPU_INVERSE)
+        return fail(DSP_GPU_EINVAL, "dsp_gpu_fft_real_batch: direction %d", direction);
+    if (bad_mem(mem)) return fail(DSP_GPU_EINVAL, "dsp_gpu_fft_real_batch: mem %d", mem);
+    // fft.h:62-63: log2n = ceil(log2(nf))
+    int log2n = 0;
+    while ((static_cast<size_t>(1) << log2n) < static_cast<size_t>(nf)) ++log2n;
+    if (log2n < 1 || log2n > 24) return fail(DSP_GPU_EINVAL, "dsp_gpu_fft_real_batch: padded size 2^%d unsupported", log2n);
+    if (batch == 0) return DSP_GPU_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (mem == DSP_GPU_MEM_DEVICE)
+        return launch_fft_real_batch(in, n_in, in_stride, static_cast<float2 *>(out), log2n, batch, direction, shifted, s);
+    const size_t in_bytes = ((batch - 1) * in_stride + n_in) * sizeof(float);
+    const size_t out_bytes = (batch << log2n) * sizeof(float2);
+    HostStage hs;
+    if (int rc = stage_in(in, in_bytes ? in_bytes : sizeof(float), out_bytes, s, &hs)) return rc;
+    if (int rc = launch_fft_real_batch(static_cast<const float *>(hs.d_in), n_in, in_stride,
+                                       static_cast<float2 *>(hs.d_out), log2n, batch, direction, shifted, s))
+        return rc;
+    return stage_out(out, out_bytes, s, hs);
+}
+
+int dsp_gpu_convolve(const float *x, float *y, size_t channels, size_t n, const float *taps, int ntaps, int mode,
+                     int mem, void *stream) {
+    if (!x || !y || !taps) return fail(DSP_GPU_EINVAL, "dsp_gpu_convolve: null buffer");
+    if (ntaps < 1 || ntaps > 4096) return fail(DSP_GPU_EINVAL, "dsp_gpu_convolve: ntaps %d outside [1,4096]", ntaps);
+    if (mode != DSP_GPU_CONV_AUTO && mode != DSP_GPU_CONV_DIRECT && mode != DSP_GPU_CONV_OVERLAP_SAVE)
+        return fail(DSP_GPU_EINVAL, "dsp_gpu_convolve: mode %d", mode);
+    if (mode == DSP_GPU_CONV_OVERLAP_SAVE && ntaps > 2049)
+        return fail(DSP_GPU_EINVAL, "dsp_gpu_convolve: overlap-save supports at most 2049 taps, got %d", ntaps);
+    if (bad_mem(mem)) return fail(DSP_GPU_EINVAL, "dsp_gpu_convolve: mem %d", mem);
+    if (channels == 0 || n == 0) return DSP_GPU_OK;
+    if (mode == DSP_GPU_CONV_AUTO)  // long filters on long signals amortise the FFT blocks
+        mode = (ntaps >= 64 && ntaps <= 2049 && n >= 4096) ? DSP_GPU_CONV_OVERLAP_SAVE : DSP_GPU_CONV_DIRECT;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    TapEntry *te = nullptr;
+    if (int rc = cached_taps(taps, ntaps, mode == DSP_GPU_CONV_OVERLAP_SAVE, s, &te)) return rc;
+    const size_t bytes = channels * n * sizeof(float);
+    const float *dx = x;
+    float *dy = y;
+    HostStage hs;
+    if (mem == DSP_GPU_MEM_HOST) {
+        if (int rc = stage_in(x, bytes, bytes, s, &hs)) return rc;
+        dx = static_cast<const float *>(hs.d_in);
+        dy = static_cast<float *>(hs.d_out);
+    }
+    int rc = mode == DSP_GPU_CONV_OVERLAP_SAVE ? launch_fir_overlap_save(dx, dy, channels, n, te->d_spectrum, ntaps, s)
+                                               : launch_fir_direct(dx, dy, channels, n, te->d_taps, ntaps, s);
+    if (rc) return rc;
+    return mem == DSP_GPU_MEM_HOST ? stage_out(y, bytes, s, hs) : DSP_GPU_OK;
+}
+
+int dsp_gpu_moving_average(const float *x, float *y, size_t channels, size_t n, int npoints, int mem, void *stream) {
+    if (!x || !y) return fail(DSP_GPU_EINVAL, "dsp_gpu_moving_average: null buffer");
+    if (npoints < 1) return fail(DSP_GPU_EINVAL, "dsp_gpu_moving_average: npoints %d < 1", npoints);
+    if (bad_mem(mem)) return fail(DSP_GPU_EINVAL, "dsp_gpu_moving_average: mem %d", mem);
+    if (channels == 0 || n == 0) return DSP_GPU_OK;
+    if (n < static_cast<size_t>(npoints))
+        return fail(DSP_GPU_EINVAL, "dsp_gpu_moving_average: n %zu < npoints %d (the reference reads out of bounds)", n, npoints);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t bytes = channels * n * sizeof(float);
+    if (mem == DSP_GPU_MEM_DEVICE) return launch_moving_average(x, y, channels, n, npoints, s);
+    HostStage hs;
+    if (int rc = stage_in(x, bytes, bytes, s, &hs)) return rc;
+    if (int rc = launch_moving_average(static_cast<const float *>(hs.d_in), static_cast<float *>(hs.d_out), channels, n,
+                                       npoints, s))
+        return rc;
+    return stage_out(y, bytes, s, hs);
+}
+
+int dsp_gpu_iir(const float *x, float *y, size_t channels, size_t n, const double *a, const double *b, int poles,
+                double c0, double d0, float *state, int mode, int mem, void *stream) {
+    if (!x || !y || !a || !b) return fail(DSP_GPU_EINVAL, "dsp_gpu_iir: null buffer");
+    if (poles < 1 || poles > 8) return fail(DSP_GPU_EINVAL, "dsp_gpu_iir: poles %d outside [1,8]", poles);
+    if (mode != DSP_GPU_IIR_AUTO && mode != DSP_GPU_IIR_BATCH && mode != DSP_GPU_IIR_SCAN)
+        return fail(DSP_GPU_EINVAL, "dsp_gpu_iir: mode %d", mode);
+    if (bad_mem(mem)) return fail(DSP_GPU_EINVAL, "dsp_gpu_iir: mem %d", mem);
+    if (channels == 0 || n == 0) return DSP_GPU_OK;
+    IirCoef co{};
+    co.poles = poles;
+    for (int i = 0; i <= poles; ++i) {
+        co.a[i] = static_cast<float>(a[i]);
+        co.b[i] = i == 0 ? 0.0f : static_cast<float>(b[i]);  // coefficients.h:93 requires b[0] == 0
+        if (!std::isfinite(co.a[i]) || !std::isfinite(co.b[i])) return fail(DSP_GPU_EINVAL, "dsp_gpu_iir: non-finite coefficient");
+    }
+    co.c0 = static_cast<float>(c0);
+    co.d0 = static_cast<float>(d0);
+    if (mode == DSP_GPU_IIR_AUTO)  // few long channels cannot fill the chip one thread per channel
+        mode = (channels < 8192 && n >= 65536) ? DSP_GPU_IIR_SCAN : DSP_GPU_IIR_BATCH;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t bytes = channels * n * sizeof(float);
+    const size_t state_bytes = channels * 2 * static_cast<size_t>(poles) * sizeof(float);
+    const float *dx = x;
+    float *dy = y;
+    float *dstate = state;
+    HostStage hs;
+    if (mem == DSP_GPU_MEM_HOST) {
+        if (int rc = stage_in(x, bytes, bytes, s, &hs)) return rc;
+        dx = static_cast<const float *>(hs.d_in);
+        dy = static_cast<float *>(hs.d_out);
+        if (state) {
+            void *p = nullptr;
+            if (int rc = workspace(WS_STATE, state_bytes, &p)) return rc;
+            dstate = static_cast<float *>(p);
+            DSPGPU_HIP(hipMemcpyAsync(dstate, state, state_bytes, hipMemcpyHostToDevice, s));
+        }
+    }
+    int rc = mode == DSP_GPU_IIR_SCAN ? launch_iir_scan(dx, dy, channels, n, co, dstate, s)
+                                      : launch_iir_batch(dx, dy, channels, n, co, dstate, s);
+    if (rc) return rc;
+    if (mem == DSP_GPU_MEM_HOST) {
+        if (state) DSPGPU_HIP(hipMemcpyAsync(state, dstate, state_bytes, hipMemcpyDeviceToHost, s));
+        return stage_out(y, bytes, s, hs);
+    }
+    return DSP_GPU_OK;
+}
+
+int dsp_gpu_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char *dsp_gpu_last_error_string(void) { return last_error_buffer(); }
+
+int dsp_gpu_shutdown(void) {
+    release_all_workspaces();
+    return DSP_GPU_OK;
+}
+
+const char *dsp_gpu_version(void) { return "dsp_gpu 0.1 (gfx950)"; }
+
+}  // extern "C"

@@ -1,0 +1,67 @@
+// common.h -- shared host-side helpers of libdsp_gpu (error plumbing, launch helpers).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+
+#include "../../include/dsp_gpu.h"
+
+namespace dspgpu {
+
+// Per-thread description of the last failure (returned by dsp_gpu_last_error_string).
+char *last_error_buffer();
+constexpr size_t kLastErrorBytes = 512;
+
+inline int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(last_error_buffer(), kLastErrorBytes, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define DSPGPU_HIP(expr)                                                                        \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess)                                                                   \
+            return ::dspgpu::fail(DSP_GPU_EHIP, "%s failed: %s (%s:%d)", #expr,                \
+                                  hipGetErrorString(e_), __FILE__, __LINE__);                   \
+    } while (0)
+
+inline int check_launch(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(DSP_GPU_EHIP, "launch of %s failed: %s", what, hipGetErrorString(e));
+    return DSP_GPU_OK;
+}
+
+// Device workspace owned by the library (one growing buffer per device and slot).
+// Slots keep independent users (host staging in/out, FFT scratch, ...) from aliasing.
+enum WorkspaceSlot { WS_STAGE_IN = 0, WS_STAGE_OUT, WS_SCRATCH_A, WS_SCRATCH_B, WS_STATE, WS_SLOTS };
+int workspace(WorkspaceSlot slot, size_t bytes, void **ptr);
+void release_all_workspaces();
+
+// ---- kernel launchers (device pointers, asynchronous on `s`) --------------------------
+int launch_fft_batch(const float2 *in, float2 *out, int log2n, size_t batch, int direction, hipStream_t s);
+int launch_fft_real_batch(const float *in, size_t n_in, size_t in_stride, float2 *out, int log2n,
+                          size_t batch, int direction, int shifted, hipStream_t s);
+int launch_fir_direct(const float *x, float *y, size_t channels, size_t n, const float *d_taps,
+                      int ntaps, hipStream_t s);
+int launch_fir_overlap_save(const float *x, float *y, size_t channels, size_t n, const float2 *d_hspec,
+                            int ntaps, hipStream_t s);
+int launch_fir_spectrum(const float *d_taps, int ntaps, float2 *d_hspec, hipStream_t s);
+int launch_moving_average(const float *x, float *y, size_t channels, size_t n, int npoints, hipStream_t s);
+
+struct IirCoef {  // fp32 device view of a Coefficients<Poles> (coefficients.h:7-15)
+    float a[9];
+    float b[9];
+    float c0, d0;
+    int poles;
+};
+int launch_iir_batch(const float *x, float *y, size_t channels, size_t n, const IirCoef &co, float *state,
+                     hipStream_t s);
+int launch_iir_scan(const float *x, float *y, size_t channels, size_t n, const IirCoef &co, float *state,
+                    hipStream_t s);
+
+}  // namespace dspgpu

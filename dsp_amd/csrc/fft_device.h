@@ -1,0 +1,191 @@
+// fft_device.h -- register-level building blocks of the Stockham FFT kernels (gfx950).
+//
+// Replaces the butterfly loop of dsp::fft0 (reference fft.h:40-54).  The reference is a
+// radix-2 decimation-in-time loop with a bit-reversal copy and a twiddle recurrence; here
+// every thread keeps P = 16 points in registers, a pass is one radix-16/8/4/2 butterfly per
+// thread, and the autosort (Stockham) indexing makes the output come out in natural order
+// with no bit-reversal pass.  SIGN = +1 is the reference's FORWARD (e^{+i 2 pi k n / N},
+// fft.h:22-29), SIGN = -1 its INVERSE; neither normalises.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+namespace dspgpu {
+
+using c32 = float2;
+#define DSP_DEV __device__ __forceinline__
+
+DSP_DEV c32 cadd(c32 a, c32 b) { return make_float2(a.x + b.x, a.y + b.y); }
+DSP_DEV c32 csub(c32 a, c32 b) { return make_float2(a.x - b.x, a.y - b.y); }
+DSP_DEV c32 cmul(c32 a, c32 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+
+// multiply by SIGN * i
+template <int SIGN>
+DSP_DEV c32 mul_i(c32 a) {
+    if constexpr (SIGN > 0) return make_float2(-a.y, a.x);
+    else return make_float2(a.y, -a.x);
+}
+
+constexpr float cos16(int q) {
+    constexpr float t[16] = {1.0f, 0.92387953251128674f, 0.70710678118654752f, 0.38268343236508977f,
+                             0.0f, -0.38268343236508977f, -0.70710678118654752f, -0.92387953251128674f,
+                             -1.0f, -0.92387953251128674f, -0.70710678118654752f, -0.38268343236508977f,
+                             0.0f, 0.38268343236508977f, 0.70710678118654752f, 0.92387953251128674f};
+    return t[q & 15];
+}
+constexpr float sin16(int q) { return cos16(q + 12); }  // sin(x) = cos(x - pi/2)
+
+// multiply by exp(SIGN * 2 pi i * Q / 16), Q a compile-time constant
+template <int Q, int SIGN>
+DSP_DEV c32 mul_w16(c32 a) {
+    constexpr int q = ((Q % 16) + 16) % 16;
+    if constexpr (q == 0) return a;
+    else if constexpr (q == 4) return mul_i<SIGN>(a);
+    else if constexpr (q == 8) return make_float2(-a.x, -a.y);
+    else if constexpr (q == 12) return mul_i<-SIGN>(a);
+    else {
+        constexpr float c = cos16(q);
+        constexpr float s = SIGN * sin16(q);
+        return make_float2(a.x * c - a.y * s, a.x * s + a.y * c);
+    }
+}
+
+template <int SIGN>
+DSP_DEV void dft2(c32 &a, c32 &b) {
+    const c32 t = a;
+    a = cadd(t, b);
+    b = csub(t, b);
+}
+
+// natural-order 4-point DFT with W4 = SIGN*i
+template <int SIGN>
+DSP_DEV void dft4(c32 &a, c32 &b, c32 &c, c32 &d) {
+    const c32 t0 = cadd(a, c), t1 = csub(a, c), t2 = cadd(b, d), t3 = mul_i<SIGN>(csub(b, d));
+    a = cadd(t0, t2);
+    b = cadd(t1, t3);
+    c = csub(t0, t2);
+    d = csub(t1, t3);
+}
+
+// In-register DFT of v[0..R), natural order in and out.
+template <int R, int SIGN>
+struct Dft;
+
+template <int SIGN>
+struct Dft<2, SIGN> {
+    static DSP_DEV void run(c32 (&v)[2]) { dft2<SIGN>(v[0], v[1]); }
+};
+template <int SIGN>
+struct Dft<4, SIGN> {
+    static DSP_DEV void run(c32 (&v)[4]) { dft4<SIGN>(v[0], v[1], v[2], v[3]); }
+};
+// 8 = 4 x 2: n = 2*n1 + n2, k = k1 + 4*k2
+template <int SIGN>
+struct Dft<8, SIGN> {
+    static DSP_DEV void run(c32 (&v)[8]) {
+        dft4<SIGN>(v[0], v[2], v[4], v[6]);  // n2 = 0 -> A[k1][0] at v[2*k1]
+        dft4<SIGN>(v[1], v[3], v[5], v[7]);  // n2 = 1 -> A[k1][1] at v[2*k1+1]
+        v[3] = mul_w16<2, SIGN>(v[3]);       // W8^{k1}
+        v[5] = mul_w16<4, SIGN>(v[5]);
+        v[7] = mul_w16<6, SIGN>(v[7]);
+        dft2<SIGN>(v[0], v[1]);
+        dft2<SIGN>(v[2], v[3]);
+        dft2<SIGN>(v[4], v[5]);
+        dft2<SIGN>(v[6], v[7]);
+        // X[k1 + 4*k2] sits at v[2*k1 + k2]
+        const c32 o1 = v[2], o2 = v[4], o3 = v[6], o4 = v[1], o5 = v[3], o6 = v[5];
+        v[1] = o1;
+        v[2] = o2;
+        v[3] = o3;
+        v[4] = o4;
+        v[5] = o5;
+        v[6] = o6;
+    }
+};
+// 16 = 4 x 4: n = 4*n1 + n2, k = k1 + 4*k2
+template <int SIGN>
+struct Dft<16, SIGN> {
+    static DSP_DEV void run(c32 (&v)[16]) {
+        dft4<SIGN>(v[0], v[4], v[8], v[12]);   // column n2: A[k1][n2] lands at v[4*k1 + n2]
+        dft4<SIGN>(v[1], v[5], v[9], v[13]);
+        dft4<SIGN>(v[2], v[6], v[10], v[14]);
+        dft4<SIGN>(v[3], v[7], v[11], v[15]);
+        v[5] = mul_w16<1, SIGN>(v[5]);  // W16^{n2*k1}
+        v[6] = mul_w16<2, SIGN>(v[6]);
+        v[7] = mul_w16<3, SIGN>(v[7]);
+        v[9] = mul_w16<2, SIGN>(v[9]);
+        v[10] = mul_w16<4, SIGN>(v[10]);
+        v[11] = mul_w16<6, SIGN>(v[11]);
+        v[13] = mul_w16<3, SIGN>(v[13]);
+        v[14] = mul_w16<6, SIGN>(v[14]);
+        v[15] = mul_w16<9, SIGN>(v[15]);
+        dft4<SIGN>(v[0], v[1], v[2], v[3]);  // row k1: X[k1 + 4*k2] lands at v[4*k1 + k2]
+        dft4<SIGN>(v[4], v[5], v[6], v[7]);
+        dft4<SIGN>(v[8], v[9], v[10], v[11]);
+        dft4<SIGN>(v[12], v[13], v[14], v[15]);
+        // 4x4 transpose of the register names
+        c32 t;
+        t = v[1]; v[1] = v[4]; v[4] = t;
+        t = v[2]; v[2] = v[8]; v[8] = t;
+        t = v[3]; v[3] = v[12]; v[12] = t;
+        t = v[6]; v[6] = v[9]; v[9] = t;
+        t = v[7]; v[7] = v[13]; v[13] = t;
+        t = v[11]; v[11] = v[14]; v[14] = t;
+    }
+};
+
+// exp(SIGN * 2 pi i * num / 2^log2den), num < 2^24 exact in fp32; sincospif is accurate
+// to ~1 ulp, which keeps the transform well inside the 1e-5*log2(N) budget (the reference
+// builds its twiddles by a double-precision recurrence, fft.h:43-44,52).
+template <int SIGN>
+DSP_DEV c32 unit_root(unsigned num, int log2den) {
+    float sn, cs;
+    sincospif(static_cast<float>(num) * __builtin_ldexpf(2.0f, -log2den), &sn, &cs);
+    return make_float2(cs, SIGN > 0 ? sn : -sn);
+}
+
+// One Stockham pass on the P register-resident points of a thread.
+//   N = 2^LOG2N points per transform, T = N/P threads per transform, `lt` = this thread's
+//   index inside its transform.  r[m] holds element lt + T*m of the pass input.
+//   The thread owns B = P/R butterflies j = lt + T*s; butterfly s reads r[s + t*B] and
+//   leaves output u in r[s + u*B].  NS = product of the radices of the earlier passes.
+template <int R, int NS, int LOG2N, int SIGN, int P>
+DSP_DEV void stockham_pass(c32 (&r)[P], int lt) {
+    constexpr int N = 1 << LOG2N;
+    constexpr int T = N / P;
+    constexpr int B = P / R;
+#pragma unroll
+    for (int s = 0; s < B; ++s) {
+        c32 v[R];
+#pragma unroll
+        for (int t = 0; t < R; ++t) v[t] = r[s + t * B];
+        if constexpr (NS > 1) {
+            constexpr int LOG2DEN = __builtin_ctz(NS * R);
+            const unsigned k = static_cast<unsigned>(lt + T * s) & (NS - 1);
+            c32 pw[R];
+            pw[1] = unit_root<SIGN>(k, LOG2DEN);
+#pragma unroll
+            for (int t = 2; t < R; ++t) pw[t] = cmul(pw[t >> 1], pw[t - (t >> 1)]);
+#pragma unroll
+            for (int t = 1; t < R; ++t) v[t] = cmul(v[t], pw[t]);
+        }
+        Dft<R, SIGN>::run(v);
+#pragma unroll
+        for (int u = 0; u < R; ++u) r[s + u * B] = v[u];
+    }
+}
+
+// Position inside the transform to which butterfly j sends its output u in a pass
+// with radix R after sub-length NS:  (j / NS) * NS * R + (j % NS) + u * NS
+template <int R, int NS>
+DSP_DEV int stockham_dest(int j, int u) {
+    return ((j & ~(NS - 1)) * R) + (j & (NS - 1)) + u * NS;
+}
+
+constexpr int radix_at(int log2n, int pass) {
+    // greedy 16,16,...,remainder
+    int left = log2n - 4 * pass;
+    return left >= 4 ? 16 : (left > 0 ? (1 << left) : 1);
+}
+
+}  // namespace dspgpu

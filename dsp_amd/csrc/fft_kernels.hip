@@ -1,0 +1,320 @@
+// fft_kernels.hip -- batched complex fp32 FFT/IFFT for gfx950 (MI355X).
+//
+// Stands in for dsp::fft0 / dsp::fft / dsp::shift (reference fft.h:31-94).
+//
+// Kernel family
+//   fft_lds_kernel<LOG2N>      4 <= log2n <= 12.  256 threads x 16 register-resident points =
+//                              4096 points per workgroup (1 transform of 4096 ... 256 of 16).
+//                              Radix-16 Stockham passes; between passes the points cross the
+//                              workgroup through one 34 KiB padded LDS image (4 workgroups/CU).
+//                              HBM traffic is exactly one coalesced 8 B read and one 8 B write
+//                              per point: 16 B/sample, the figure the roofline is quoted on.
+//   fft_tiny_kernel<LOG2N>     log2n <= 3: one thread per transform, registers only.
+//   fft_column_kernel<LOG2L>   building block of large transforms (13 <= log2n <= 24): FFTs of
+//                              length L <= 256 down the middle axis of an [A][L][B] view, 16
+//                              adjacent columns per workgroup so every global access is a 128 B
+//                              run; fuses the inter-step twiddle and the transposed store.  A
+//                              transform of 2^13..2^16 points takes two such passes, 2^17..2^24
+//                              three (the classic four-/six-step decomposition, all on one GPU).
+#include <algorithm>
+
+#include "common.h"
+#include "fft_lds_core.h"
+
+namespace dspgpu {
+namespace {
+
+// REAL_IN: rows of real samples, zero padded (fft.h:65-74).  SHIFTED: dsp::shift fused (fft.h:85-94).
+template <int LOG2N, int SIGN, bool REAL_IN, bool SHIFTED>
+__global__ __launch_bounds__(kThreads) void fft_lds_kernel(const void *__restrict__ in_, c32 *__restrict__ out,
+                                                           size_t batch, size_t n_in, size_t in_stride) {
+    constexpr int N = 1 << LOG2N;
+    constexpr int T = N / kPoints;     // threads per transform
+    constexpr int G = kThreads / T;    // transforms per workgroup
+    __shared__ c32 lds[kLdsElems];
+
+    const int tid = threadIdx.x;
+    const int g = tid / T;
+    const int lt = tid % T;
+    const size_t xf = static_cast<size_t>(blockIdx.x) * G + g;
+    const bool live = xf < batch;
+
+    c32 r[kPoints];
+    if (live) {
+        if constexpr (REAL_IN) {
+            const float *src = static_cast<const float *>(in_) + xf * in_stride;
+#pragma unroll
+            for (int m = 0; m < kPoints; ++m) {
+                const size_t i = lt + T * m;
+                r[m] = make_float2(i < n_in ? src[i] : 0.0f, 0.0f);
+            }
+        } else {
+            const c32 *src = static_cast<const c32 *>(in_) + xf * N;
+#pragma unroll
+            for (int m = 0; m < kPoints; ++m) r[m] = src[lt + T * m];
+        }
+    } else {
+#pragma unroll
+        for (int m = 0; m < kPoints; ++m) r[m] = make_float2(0.0f, 0.0f);
+    }
+
+    fft_passes<LOG2N, SIGN>(r, lds, lt, g * N);
+
+    if (live) {
+        c32 *dst = out + xf * N;
+#pragma unroll
+        for (int m = 0; m < kPoints; ++m) {
+            int k = lt + T * m;
+            if constexpr (SHIFTED) k = (k + N / 2) & (N - 1);
+            dst[k] = r[m];
+        }
+    }
+}
+
+template <int LOG2N, int SIGN, bool REAL_IN, bool SHIFTED>
+__global__ __launch_bounds__(kThreads) void fft_tiny_kernel(const void *__restrict__ in_, c32 *__restrict__ out,
+                                                            size_t batch, size_t n_in, size_t in_stride) {
+    constexpr int N = 1 << LOG2N;
+    const size_t xf = static_cast<size_t>(blockIdx.x) * kThreads + threadIdx.x;
+    if (xf >= batch) return;
+    c32 v[N];
+    if constexpr (REAL_IN) {
+        const float *src = static_cast<const float *>(in_) + xf * in_stride;
+#pragma unroll
+        for (int m = 0; m < N; ++m) v[m] = make_float2(static_cast<size_t>(m) < n_in ? src[m] : 0.0f, 0.0f);
+    } else {
+        const c32 *src = static_cast<const c32 *>(in_) + xf * N;
+#pragma unroll
+        for (int m = 0; m < N; ++m) v[m] = src[m];
+    }
+    Dft<N, SIGN>::run(v);
+    c32 *dst = out + xf * N;
+#pragma unroll
+    for (int m = 0; m < N; ++m) dst[SHIFTED ? ((m + N / 2) & (N - 1)) : m] = v[m];
+}
+
+// ---- column pass of a large transform -----------------------------------------------------
+// View: in[a][l][b], l < L = 2^LOG2L, b < B (contiguous).  For every (a, b) column: FFT over l,
+// output element k multiplied by exp(SIGN*2 pi i * k*(b/Bi) / 2^tw_log2) when tw_log2 > 0,
+// stored at out[a*L*B + (b/Bi)*s_hi + k*s_k + (b%Bi)].  A workgroup owns C = 4096/L adjacent
+// columns (C >= 16 because L <= 256); the LDS image is [position][column] so neighbouring
+// lanes (columns) touch neighbouring banks in every access and no padding is needed.
+struct ColumnPlan {
+    size_t B;      // inner contiguous extent
+    size_t Bi;     // b is split as (b / Bi, b % Bi)
+    size_t s_hi;   // output stride of b / Bi
+    size_t s_k;    // output stride of k
+    int tw_log2;   // log2 of the twiddle modulus, 0 = no twiddle
+};
+
+template <int R, int NS, int LOG2L, int C>
+DSP_DEV void column_exchange(c32 (&r)[kPoints], c32 *lds, int lt, int c) {
+    constexpr int T = (1 << LOG2L) / kPoints;
+    constexpr int Bf = kPoints / R;
+#pragma unroll
+    for (int s = 0; s < Bf; ++s) {
+        const int j = lt + T * s;
+#pragma unroll
+        for (int u = 0; u < R; ++u) lds[stockham_dest<R, NS>(j, u) * C + c] = r[s + u * Bf];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < kPoints; ++m) r[m] = lds[(lt + T * m) * C + c];
+}
+
+template <int LOG2L, int SIGN>
+__global__ __launch_bounds__(kThreads) void fft_column_kernel(const c32 *__restrict__ in, c32 *__restrict__ out,
+                                                              ColumnPlan plan, size_t columns_per_a) {
+    constexpr int L = 1 << LOG2L;
+    constexpr int T = L / kPoints;   // threads per column
+    constexpr int C = kThreads / T;  // columns per workgroup
+    __shared__ c32 lds[kTile];
+
+    const int tid = threadIdx.x;
+    const int c = tid % C;
+    const int lt = tid / C;
+    const size_t tile = blockIdx.x;                       // tiles never straddle an `a` slab: B % C == 0
+    const size_t tiles_per_a = columns_per_a / C;
+    const size_t a = tile / tiles_per_a;
+    const size_t b = (tile % tiles_per_a) * C + c;
+    const c32 *src = in + a * L * plan.B + b;
+
+    c32 r[kPoints];
+#pragma unroll
+    for (int m = 0; m < kPoints; ++m) r[m] = src[static_cast<size_t>(lt + T * m) * plan.B];
+
+    constexpr int R0 = radix_at(LOG2L, 0), R1 = radix_at(LOG2L, 1);
+    stockham_pass<R0, 1, LOG2L, SIGN, kPoints>(r, lt);
+    if constexpr (R1 > 1) {
+        column_exchange<R0, 1, LOG2L, C>(r, lds, lt, c);
+        stockham_pass<R1, R0, LOG2L, SIGN, kPoints>(r, lt);
+    }
+
+    const size_t bhi = b / plan.Bi, blo = b % plan.Bi;
+    c32 *dst = out + a * L * plan.B + bhi * plan.s_hi + blo;
+#pragma unroll
+    for (int m = 0; m < kPoints; ++m) {
+        const unsigned k = lt + T * m;
+        c32 v = r[m];
+        if (plan.tw_log2 > 0) {
+            const unsigned e = (k * static_cast<unsigned>(bhi)) & ((1u << plan.tw_log2) - 1u);
+            v = cmul(v, unit_root<SIGN>(e, plan.tw_log2));
+        }
+        dst[static_cast<size_t>(k) * plan.s_k] = v;
+    }
+}
+
+// real rows -> zero padded complex rows (front end of the large real-input path)
+__global__ __launch_bounds__(kThreads) void pack_real_kernel(const float *__restrict__ in, c32 *__restrict__ out,
+                                                             size_t n_in, size_t in_stride, size_t n, size_t total) {
+    for (size_t i = static_cast<size_t>(blockIdx.x) * kThreads + threadIdx.x; i < total;
+         i += static_cast<size_t>(gridDim.x) * kThreads) {
+        const size_t row = i / n, col = i % n;
+        out[i] = make_float2(col < n_in ? in[row * in_stride + col] : 0.0f, 0.0f);
+    }
+}
+
+// dsp::shift (fft.h:85-94) for the large path: rotating a power-of-two row by n/2 is a swap
+// of its halves, done in place (one thread per pair).
+__global__ __launch_bounds__(kThreads) void swap_halves_kernel(c32 *__restrict__ data, size_t n, size_t pairs) {
+    const size_t half = n / 2;
+    for (size_t i = static_cast<size_t>(blockIdx.x) * kThreads + threadIdx.x; i < pairs;
+         i += static_cast<size_t>(gridDim.x) * kThreads) {
+        const size_t row = i / half, col = i % half;
+        c32 *p = data + row * n + col;
+        const c32 lo = p[0], hi = p[half];
+        p[0] = hi;
+        p[half] = lo;
+    }
+}
+
+// ---- host-side dispatch ---------------------------------------------------------------------
+template <int LOG2N, bool REAL_IN, bool SHIFTED>
+int launch_small(const void *in, c32 *out, size_t batch, size_t n_in, size_t in_stride, int direction,
+                 hipStream_t s) {
+    if constexpr (LOG2N >= 4) {
+        constexpr int G = kThreads / ((1 << LOG2N) / kPoints);
+        const size_t blocks = (batch + G - 1) / G;
+        if (direction == DSP_GPU_FORWARD)
+            hipLaunchKernelGGL((fft_lds_kernel<LOG2N, +1, REAL_IN, SHIFTED>), dim3(blocks), dim3(kThreads), 0, s, in,
+                               out, batch, n_in, in_stride);
+        else
+            hipLaunchKernelGGL((fft_lds_kernel<LOG2N, -1, REAL_IN, SHIFTED>), dim3(blocks), dim3(kThreads), 0, s, in,
+                               out, batch, n_in, in_stride);
+    } else {
+        const size_t blocks = (batch + kThreads - 1) / kThreads;
+        if (direction == DSP_GPU_FORWARD)
+            hipLaunchKernelGGL((fft_tiny_kernel<LOG2N, +1, REAL_IN, SHIFTED>), dim3(blocks), dim3(kThreads), 0, s, in,
+                               out, batch, n_in, in_stride);
+        else
+            hipLaunchKernelGGL((fft_tiny_kernel<LOG2N, -1, REAL_IN, SHIFTED>), dim3(blocks), dim3(kThreads), 0, s, in,
+                               out, batch, n_in, in_stride);
+    }
+    return check_launch("fft_lds_kernel");
+}
+
+template <bool REAL_IN, bool SHIFTED>
+int dispatch_small(int log2n, const void *in, c32 *out, size_t batch, size_t n_in, size_t in_stride, int direction,
+                   hipStream_t s) {
+    switch (log2n) {
+#define DSP_CASE(K) \
+    case K: return launch_small<K, REAL_IN, SHIFTED>(in, out, batch, n_in, in_stride, direction, s);
+        DSP_CASE(1) DSP_CASE(2) DSP_CASE(3) DSP_CASE(4) DSP_CASE(5) DSP_CASE(6) DSP_CASE(7) DSP_CASE(8)
+        DSP_CASE(9) DSP_CASE(10) DSP_CASE(11) DSP_CASE(12)
+#undef DSP_CASE
+    default: return fail(DSP_GPU_EINVAL, "log2n %d outside the single-pass range", log2n);
+    }
+}
+
+int launch_column(int log2l, const c32 *in, c32 *out, const ColumnPlan &plan, size_t slabs, int direction,
+                  hipStream_t s) {
+    const int L = 1 << log2l;
+    const int C = kTile / L;
+    if (plan.B % C != 0) return fail(DSP_GPU_EINVAL, "column pass: inner extent %zu not a multiple of %d", plan.B, C);
+    const size_t blocks = slabs * (plan.B / C);
+    switch (log2l) {
+#define DSP_CASE(K)                                                                                              \
+    case K:                                                                                                      \
+        if (direction == DSP_GPU_FORWARD)                                                                        \
+            hipLaunchKernelGGL((fft_column_kernel<K, +1>), dim3(blocks), dim3(kThreads), 0, s, in, out, plan, plan.B); \
+        else                                                                                                     \
+            hipLaunchKernelGGL((fft_column_kernel<K, -1>), dim3(blocks), dim3(kThreads), 0, s, in, out, plan, plan.B); \
+        break;
+        DSP_CASE(4) DSP_CASE(5) DSP_CASE(6) DSP_CASE(7) DSP_CASE(8)
+#undef DSP_CASE
+    default: return fail(DSP_GPU_EINVAL, "column pass length 2^%d unsupported", log2l);
+    }
+    return check_launch("fft_column_kernel");
+}
+
+// Large transform: N = N1*N2 (two column passes) or N1*N2*N3 (three), every factor <= 256.
+//   step 1  [n1][rest]      FFT over n1, twiddle W_N^{k1*rest}, transposed store -> [rest][k1]
+//   step 2  [n2][n3][k1]    FFT over n2, twiddle W_{N2N3}^{k2*n3}                -> [n3][k2][k1]
+//   step 3  [n3][k2 k1]     FFT over n3                                           -> [k3][k2 k1] = natural order
+// (with two factors step 2 is the last one and carries no twiddle).  Ping-pongs between
+// `out` and one scratch buffer so the input is never modified.
+int launch_large(const c32 *in, c32 *out, int log2n, size_t batch, int direction, hipStream_t s) {
+    const size_t n = static_cast<size_t>(1) << log2n;
+    const int steps = log2n <= 16 ? 2 : 3;
+    int lg[3] = {0, 0, 0};
+    for (int i = 0, left = log2n; i < steps; ++i) {
+        lg[i] = (left + (steps - i) - 1) / (steps - i);
+        left -= lg[i];
+    }
+    void *scratch_v = nullptr;
+    if (int rc = workspace(WS_SCRATCH_A, batch * n * sizeof(c32), &scratch_v)) return rc;
+    c32 *scratch = static_cast<c32 *>(scratch_v);
+    const size_t n1 = static_cast<size_t>(1) << lg[0], n2 = static_cast<size_t>(1) << lg[1];
+    if (steps == 2) {
+        ColumnPlan p1{n2, 1, n1, 1, log2n};
+        if (int rc = launch_column(lg[0], in, scratch, p1, batch, direction, s)) return rc;
+        ColumnPlan p2{n1, n1, 0, n1, 0};
+        return launch_column(lg[1], scratch, out, p2, batch, direction, s);
+    }
+    const size_t n3 = static_cast<size_t>(1) << lg[2];
+    const ColumnPlan p1{n2 * n3, 1, n1, 1, log2n};
+    const ColumnPlan p2{n3 * n1, n1, n2 * n1, n1, lg[1] + lg[2]};
+    const ColumnPlan p3{n2 * n1, n2 * n1, 0, n2 * n1, 0};
+    if (in != out) {
+        if (int rc = launch_column(lg[0], in, out, p1, batch, direction, s)) return rc;       // in -> out
+        if (int rc = launch_column(lg[1], out, scratch, p2, batch, direction, s)) return rc;  // out -> scratch
+        return launch_column(lg[2], scratch, out, p3, batch, direction, s);                   // scratch -> out
+    }
+    // in place: a column pass may not overwrite its own input, so finish in scratch and copy back
+    if (int rc = launch_column(lg[0], in, scratch, p1, batch, direction, s)) return rc;
+    if (int rc = launch_column(lg[1], scratch, out, p2, batch, direction, s)) return rc;
+    if (int rc = launch_column(lg[2], out, scratch, p3, batch, direction, s)) return rc;
+    DSPGPU_HIP(hipMemcpyAsync(out, scratch, batch * n * sizeof(c32), hipMemcpyDeviceToDevice, s));
+    return DSP_GPU_OK;
+}
+
+}  // namespace
+
+int launch_fft_batch(const float2 *in, float2 *out, int log2n, size_t batch, int direction, hipStream_t s) {
+    if (batch == 0) return DSP_GPU_OK;
+    if (log2n <= 12) return dispatch_small<false, false>(log2n, in, out, batch, 0, 0, direction, s);
+    return launch_large(in, out, log2n, batch, direction, s);
+}
+
+int launch_fft_real_batch(const float *in, size_t n_in, size_t in_stride, float2 *out, int log2n, size_t batch,
+                          int direction, int shifted, hipStream_t s) {
+    if (batch == 0) return DSP_GPU_OK;
+    if (log2n <= 12) {
+        if (shifted) return dispatch_small<true, true>(log2n, in, out, batch, n_in, in_stride, direction, s);
+        return dispatch_small<true, false>(log2n, in, out, batch, n_in, in_stride, direction, s);
+    }
+    const size_t n = static_cast<size_t>(1) << log2n;
+    const size_t total = batch * n;
+    void *packed_v = nullptr;
+    if (int rc = workspace(WS_SCRATCH_B, total * sizeof(c32), &packed_v)) return rc;
+    c32 *packed = static_cast<c32 *>(packed_v);
+    const unsigned grid = static_cast<unsigned>(std::min<size_t>((total + kThreads - 1) / kThreads, 2048 * 8));
+    hipLaunchKernelGGL(pack_real_kernel, dim3(grid), dim3(kThreads), 0, s, in, packed, n_in, in_stride, n, total);
+    if (int rc = check_launch("pack_real_kernel")) return rc;
+    if (int rc = launch_large(packed, out, log2n, batch, direction, s)) return rc;
+    if (!shifted) return DSP_GPU_OK;
+    hipLaunchKernelGGL(swap_halves_kernel, dim3(grid), dim3(kThreads), 0, s, out, n, total / 2);
+    return check_launch("swap_halves_kernel");
+}
+
+}  // namespace dspgpu

@@ -1,0 +1,154 @@
+"""Host-side mirror of the reference's hot-path interface, on top of the C ABI.
+
+Names and argument meaning follow the reference (file:line relative to its dsp/include/dsp/):
+
+    fft0(x, inverse)                  fft.h:31-55      complex [.., 2^k] -> complex, unnormalised
+    fft(x_real, nf, inverse, shift)   fft.h:57-94      real rows, zero padded to 2^ceil(log2 nf)
+    convolve(x, taps, mode)           convolution.h:8-29 / filter.h:123-140
+    moving_average(x, npoints)        filter.h:81-101
+    iir(x, a, b, c0, d0, state, mode) coefficients.h:88-130,172-195
+
+Inputs are torch CUDA tensors (device pointers, asynchronous on the current torch stream)
+or numpy arrays (host pointers, staged by the library).  fp32 only.  No CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+
+try:  # torch is plumbing for device memory / streams only
+    import torch
+except Exception:  # pragma: no cover
+    torch = None
+
+
+def _is_torch(x) -> bool:
+    return torch is not None and isinstance(x, torch.Tensor)
+
+
+def _stream_of(x) -> int:
+    if _is_torch(x) and x.is_cuda:
+        return torch.cuda.current_stream(x.device).cuda_stream
+    return 0
+
+
+def _prep(x, dtype_np, dtype_torch_name):
+    """-> (contiguous array/tensor, data pointer, mem flag)"""
+    if _is_torch(x):
+        want = getattr(torch, dtype_torch_name)
+        if not x.is_cuda:
+            raise capi.DspGpuError(capi.EINVAL, "torch tensors must live on the GPU (pass numpy for host memory)")
+        if x.dtype != want:
+            raise capi.DspGpuError(capi.EINVAL, f"expected {want}, got {x.dtype}")
+        x = x.contiguous()
+        return x, x.data_ptr(), capi.MEM_DEVICE
+    x = np.ascontiguousarray(x, dtype=dtype_np)
+    return x, x.ctypes.data, capi.MEM_HOST
+
+
+def _empty_like(x, shape, dtype_np, dtype_torch_name):
+    if _is_torch(x):
+        return torch.empty(shape, dtype=getattr(torch, dtype_torch_name), device=x.device)
+    return np.empty(shape, dtype=dtype_np)
+
+
+def _ptr(a):
+    return a.data_ptr() if _is_torch(a) else a.ctypes.data
+
+
+def fft0(x, inverse: bool = False, out=None):
+    """Batched complex FFT over the last axis (length 2^k, k in 1..24).  fft.h:31-55."""
+    x, px, mem = _prep(x, np.complex64, "complex64")
+    n = x.shape[-1]
+    log2n = int(n).bit_length() - 1
+    if n < 2 or (1 << log2n) != n:
+        raise capi.DspGpuError(capi.EINVAL, f"transform length {n} is not a power of two >= 2")
+    batch = int(np.prod(x.shape[:-1])) if x.ndim > 1 else 1
+    if out is None:
+        out = _empty_like(x, tuple(x.shape), np.complex64, "complex64")
+    capi.check(capi.lib().dsp_gpu_fft_batch(px, _ptr(out), log2n, batch, capi.INVERSE if inverse else capi.FORWARD,
+                                            mem, _stream_of(x)))
+    return out
+
+
+def fft(x, nf: int, inverse: bool = False, shift: bool = False):
+    """Real-input wrapper dsp::fft (fft.h:57-83), optionally followed by dsp::shift (fft.h:85-94)."""
+    x, px, mem = _prep(x, np.float32, "float32")
+    n_in = x.shape[-1]
+    batch = int(np.prod(x.shape[:-1])) if x.ndim > 1 else 1
+    log2n = max(1, int(np.ceil(np.log2(nf))))
+    out = _empty_like(x, tuple(x.shape[:-1]) + (1 << log2n,), np.complex64, "complex64")
+    capi.check(capi.lib().dsp_gpu_fft_real_batch(px, n_in, n_in, _ptr(out), int(nf), batch,
+                                                 capi.INVERSE if inverse else capi.FORWARD, int(shift), mem,
+                                                 _stream_of(x)))
+    return out
+
+
+_MODES = {"auto": capi.CONV_AUTO, "direct": capi.CONV_DIRECT, "time": capi.CONV_DIRECT,
+          "overlap_save": capi.CONV_OVERLAP_SAVE, "frequency": capi.CONV_OVERLAP_SAVE}
+
+
+def convolve(x, taps, mode: str = "auto"):
+    """Causal FIR, first len(taps)-1 outputs zero.  x: [n] or [channels, n] fp32.  filter.h:123-140."""
+    x, px, mem = _prep(x, np.float32, "float32")
+    taps = np.ascontiguousarray(taps, dtype=np.float32)  # the designers produce double; the device runs fp32
+    n = x.shape[-1]
+    channels = int(np.prod(x.shape[:-1])) if x.ndim > 1 else 1
+    y = _empty_like(x, tuple(x.shape), np.float32, "float32")
+    capi.check(capi.lib().dsp_gpu_convolve(px, _ptr(y), channels, n, taps.ctypes.data, taps.size, _MODES[mode], mem,
+                                           _stream_of(x)))
+    return y
+
+
+def moving_average(x, npoints: int):
+    """Centred moving average, zero edges.  filter.h:81-101."""
+    x, px, mem = _prep(x, np.float32, "float32")
+    n = x.shape[-1]
+    channels = int(np.prod(x.shape[:-1])) if x.ndim > 1 else 1
+    y = _empty_like(x, tuple(x.shape), np.float32, "float32")
+    capi.check(capi.lib().dsp_gpu_moving_average(px, _ptr(y), channels, n, int(npoints), mem, _stream_of(x)))
+    return y
+
+
+_IIR_MODES = {"auto": capi.IIR_AUTO, "batch": capi.IIR_BATCH, "scan": capi.IIR_SCAN}
+
+
+def iir(x, a, b, c0: float = 1.0, d0: float = 0.0, state=None, mode: str = "auto"):
+    """IIR recursion with feedback ADDED (coefficients.h:106-130).  state: [channels, 2*poles] fp32, updated in place."""
+    x, px, mem = _prep(x, np.float32, "float32")
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    if a.size != b.size:
+        raise capi.DspGpuError(capi.EINVAL, "a and b must have poles+1 entries each")
+    poles = a.size - 1
+    n = x.shape[-1]
+    channels = int(np.prod(x.shape[:-1])) if x.ndim > 1 else 1
+    y = _empty_like(x, tuple(x.shape), np.float32, "float32")
+    pstate = None
+    if state is not None:
+        if _is_torch(state) != _is_torch(x):
+            raise capi.DspGpuError(capi.EINVAL, "state must live where x lives")
+        if _is_torch(state):
+            if not (state.is_contiguous() and state.dtype == torch.float32 and state.numel() == channels * 2 * poles):
+                raise capi.DspGpuError(capi.EINVAL, "state must be contiguous fp32 [channels, 2*poles]")
+        elif not (state.flags.c_contiguous and state.dtype == np.float32 and state.size == channels * 2 * poles):
+            raise capi.DspGpuError(capi.EINVAL, "state must be contiguous fp32 [channels, 2*poles]")
+        pstate = _ptr(state)
+    capi.check(capi.lib().dsp_gpu_iir(px, _ptr(y), channels, n, a.ctypes.data, b.ctypes.data, poles, float(c0),
+                                      float(d0), pstate, _IIR_MODES[mode], mem, _stream_of(x)))
+    return y
+
+
+def fft_kernel_ms(x, out, inverse: bool, iters: int) -> float:
+    """Average milliseconds per batched-FFT launch, timed with HIP events on x's stream."""
+    n = x.shape[-1]
+    log2n = int(n).bit_length() - 1
+    batch = x.numel() // n
+    ms = C.c_float(0.0)
+    capi.check(capi.lib().dsp_gpu_fft_batch_timed(x.data_ptr(), out.data_ptr(), log2n, batch,
+                                                  capi.INVERSE if inverse else capi.FORWARD, int(iters), C.byref(ms),
+                                                  _stream_of(x)))
+    return float(ms.value)

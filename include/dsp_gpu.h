@@ -1,0 +1,135 @@
+/*
+ * dsp_gpu.h -- C ABI of libdsp_gpu.so: the MI355X (gfx950) implementation of the
+ * ejosiah/dsp numeric hot path (radix-2 FFT/IFFT, FIR convolution, IIR recursion).
+ *
+ * The reference has no FFI / plugin seam: its hot path sits directly
+ * behind C++ templates.  Each entry point below names the reference function(s) it
+ * stands in for (file:line relative to the reference's dsp/include/dsp/).  The C++
+ * drop-in overloads that keep the reference's own signatures are in
+ * include/dsp_mi355x/ and call only this header.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; `stream` is a hipStream_t passed as void* (NULL =
+ *     the default stream).
+ *   - `mem` says where the data pointers live: DSP_GPU_MEM_DEVICE (device pointers, the
+ *     call is asynchronous on `stream`) or DSP_GPU_MEM_HOST (host pointers, the library
+ *     stages through its own device workspace and the call returns when `out` is ready).
+ *     Small parameter arrays (taps, a, b) are ALWAYS host pointers.
+ *   - every function returns DSP_GPU_OK (0) or a negative DSP_GPU_E* code; nothing
+ *     throws or aborts across this boundary.  dsp_gpu_last_error_string() describes the
+ *     last failure on the calling thread.
+ *   - the caller owns every buffer it passes.  The library owns per-device workspaces
+ *     and cached tap uploads, released by dsp_gpu_shutdown().
+ *   - re-entrant; intended multi-GPU use is one host thread (or process) per device with
+ *     that device made current (hipSetDevice) before the call.
+ */
+#ifndef DSP_GPU_H
+#define DSP_GPU_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* error codes */
+#define DSP_GPU_OK            0
+#define DSP_GPU_EINVAL       (-1) /* bad argument (NULL pointer, size out of range, ...) */
+#define DSP_GPU_EHIP         (-2) /* a HIP runtime call failed                         */
+#define DSP_GPU_ENOMEM       (-3) /* workspace allocation failed                        */
+#define DSP_GPU_EUNSUPPORTED (-4) /* valid request this build does not implement        */
+
+/* direction: the reference's FFTType (fft.h:9).  FORWARD uses e^{+i 2 pi k n / N}
+ * (fft.h:22-29,44 -- the conjugate of the numpy/FFTW "forward"); neither direction
+ * normalises (fft.h:40-54). */
+#define DSP_GPU_FORWARD 0
+#define DSP_GPU_INVERSE 1
+
+#define DSP_GPU_MEM_HOST   0
+#define DSP_GPU_MEM_DEVICE 1
+
+/* convolution mode (the reference's dsp::Domain, dsp.h:14: Time -> DIRECT, Frequency -> OVERLAP_SAVE) */
+#define DSP_GPU_CONV_AUTO         0
+#define DSP_GPU_CONV_DIRECT       1
+#define DSP_GPU_CONV_OVERLAP_SAVE 2
+
+/* IIR execution mode */
+#define DSP_GPU_IIR_AUTO  0
+#define DSP_GPU_IIR_BATCH 1 /* one thread per channel, channels in parallel          */
+#define DSP_GPU_IIR_SCAN  2 /* block-parallel linear-recurrence scan inside a channel */
+
+/*
+ * Batched complex FFT.  Replaces dsp::fft0<type>(in, out, log2n) (fft.h:31-55) for
+ * `batch` independent transforms of n = 2^log2n points, fp32 instead of the
+ * reference's double.  Interleaved (re,im) float pairs; transform b is at
+ * in + b*2*n floats.  Natural-order output, unnormalised.  in == out is allowed.
+ * 1 <= log2n <= 24.
+ */
+int dsp_gpu_fft_batch(const void *in, void *out, int log2n, size_t batch, int direction, int mem,
+                      void *stream);
+
+/*
+ * Batched real-input FFT wrapper.  Replaces dsp::fft(first, last, c_out, nf) (fft.h:57-83):
+ * each of `batch` rows holds n_in real samples (row stride in_stride floats); a row is
+ * zero-padded to n = 2^ceil(log2 nf) (samples beyond n are ignored, as in the reference),
+ * transformed with fft0 semantics and written as n interleaved complex values.
+ * `shifted` != 0 additionally applies dsp::shift (fft.h:85-94) to each output row.
+ */
+int dsp_gpu_fft_real_batch(const float *in, size_t n_in, size_t in_stride, void *out, int nf,
+                           size_t batch, int direction, int shifted, int mem, void *stream);
+
+/*
+ * FIR convolution.  Replaces dsp::filter::SincFilter<>::apply (filter.h:123-140) and
+ * dsp::convolve<T, Domain> (convolution.h:8-29; its Frequency branch, which the reference
+ * only declares, is DSP_GPU_CONV_OVERLAP_SAVE here).  Channel-major x[ch][n], y[ch][n];
+ * y[ch][j] = sum_{i<ntaps} x[ch][j-i]*taps[i] for j >= ntaps-1 and 0 before that
+ * (filter.h:133 -- causal, first ntaps-1 outputs zero).  `taps` is a HOST pointer to
+ * ntaps floats shared by all channels (e.g. the fp32 cast of dsp::sinc, dsp.h:47-79).
+ * 1 <= ntaps <= 4096 (direct), ntaps <= 2049 (overlap-save).
+ */
+int dsp_gpu_convolve(const float *x, float *y, size_t channels, size_t n, const float *taps,
+                     int ntaps, int mode, int mem, void *stream);
+
+/*
+ * Centred moving average.  Replaces dsp::filter::MovingAverageFilter::apply
+ * (filter.h:81-101): y[i] = mean(x[i-mid .. i-mid+npoints-1]) for mid <= i < n-mid with
+ * mid = npoints/2, zero elsewhere.  Windows are summed directly (no running sum), so the
+ * result does not carry the reference's accumulated rounding drift.  n >= npoints >= 1.
+ */
+int dsp_gpu_moving_average(const float *x, float *y, size_t channels, size_t n, int npoints,
+                           int mem, void *stream);
+
+/*
+ * IIR recursion.  Replaces dsp::Coefficients<Poles>::operator()(const SampleBuffer&)
+ * (coefficients.h:88-130, and the BiQuad form :172-195):
+ *     v[t] = sum_{i=0..poles} a[i] x[t-i] + sum_{i=1..poles} b[i] v[t-i]   (feedback ADDED)
+ *     y[t] = v[t]*c0 + x[t]*d0
+ * a, b: HOST pointers to poles+1 doubles (b[0] ignored), as produced by the designers in
+ * recursive_filters.h.  1 <= poles <= 8.  Channel-major x[ch][n], y[ch][n].
+ * `state` (may be NULL = start from rest, nothing written back) is [ch][2*poles] floats,
+ * {x[t-1..t-poles], v[t-1..t-poles]} per channel, read before and written after the call:
+ * it is the reference's x[]/y[] history (coefficients.h:11-12) made explicit so a long
+ * channel can be fed in chunks.  Lives where `mem` says.
+ */
+int dsp_gpu_iir(const float *x, float *y, size_t channels, size_t n, const double *a,
+                const double *b, int poles, double c0, double d0, float *state, int mode, int mem,
+                void *stream);
+
+/* housekeeping */
+int dsp_gpu_device_count(void);
+const char *dsp_gpu_last_error_string(void);
+int dsp_gpu_shutdown(void); /* frees workspaces / cached taps of every device this process used */
+const char *dsp_gpu_version(void);
+
+/*
+ * Kernel-only timing helper for the bench harness: runs `iters` back-to-back launches of
+ * the batched FFT on `stream` between two HIP events recorded on that same stream and
+ * returns the average milliseconds per launch in *ms_per_launch (device pointers only).
+ */
+int dsp_gpu_fft_batch_timed(const void *in, void *out, int log2n, size_t batch, int direction,
+                            int iters, float *ms_per_launch, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DSP_GPU_H */
