@@ -1,0 +1,280 @@
+#!/usr/bin/env python3
+"""Benchmark of the MI355X hot path (BASELINE.json metric), one JSON line on stdout.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload fft|fir_direct|fir_os|iir_batch|iir_scan|mavg]
+
+Default workload = BASELINE.json configs[1]: 65,536 x 4096-point complex fp32 FFT (FORWARD) of
+synthetic N(0,1) noise, inputs resident in HBM.  A "step" is one pass of the hot path over that
+batch through the C ABI (dsp_gpu_fft_batch).  N > 1: launched by torch.distributed.run, one rank
+per GPU; channels are independent, so every rank owns its own batch of the same size (weak
+scaling, no data-path collective) and `value` = samples all ranks processed / max-over-ranks time.
+
+`roofline`     algorithmic bytes (or flops) of one launch / average launch time measured with
+               HIP events recorded on the stream the launches go to, over the timed region.
+`cpu_baseline` the reference's own code (oracle/_ref, kind "reference") if that library
+               travelled with the tree, else the oracle restatement (kind "port"), single
+               thread (the reference is single-threaded), on a bounded sample of the workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+FP32_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: peak fp32 vector (= fp32 MFMA) rate
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="fft",
+                    choices=["fft", "fir_direct", "fir_os", "iir_batch", "iir_scan", "mavg"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the CPU baseline sample")
+    return ap.parse_args()
+
+
+# ----------------------------------------------------------------------------------------------
+# workloads: each returns (step_fn, units_per_step, meta)
+# ----------------------------------------------------------------------------------------------
+def make_fft(torch, dev, ops, rank):
+    batch, n = 65536, 4096
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    x = torch.view_as_complex(torch.randn(batch, n, 2, device=dev, generator=g))
+    out = torch.empty_like(x)
+
+    def step():
+        ops.fft0(x, False, out=out)
+
+    meta = dict(metric="batched_fft_throughput", unit="GSamples/s", dtype="f32",
+                config={"workload": "C2: 65,536 x 4096-point complex fp32 FFT (FORWARD), N(0,1) noise, per GPU",
+                        "batch": batch, "n": n, "sharding": "channels, no collective"},
+                bound="hbm", alg_per_unit=16.0, alg_unit="bytes/sample (8 B read + 8 B write)",
+                kernel="fft_lds_kernel<12>")
+    return step, batch * n, meta
+
+
+def make_fir(torch, dev, ops, rank, mode):
+    channels, n, ntaps = 1024, 1 << 20, 511
+    taps = sinc_taps_host(0.1, ntaps)
+    g = torch.Generator(device=dev).manual_seed(4321 + rank)
+    x = torch.randn(channels, n, device=dev, generator=g)
+    y = torch.empty_like(x)
+
+    def step():
+        ops.convolve(x, taps, mode, out=y)
+
+    if mode == "direct":
+        meta = dict(metric="fir_direct_throughput", unit="GMAC/s", dtype="f32", bound="mfma",
+                    alg_per_unit=2.0, alg_unit="flop/MAC", kernel="fir_direct_kernel")
+        units = channels * (n - (ntaps - 1)) * ntaps
+    else:
+        meta = dict(metric="fir_overlap_save_throughput", unit="GSamples/s", dtype="f32", bound="hbm",
+                    alg_per_unit=8.0, alg_unit="bytes/sample (4 B read + 4 B write)", kernel="fir_overlap_save_kernel")
+        units = channels * n
+    meta["config"] = {"workload": f"C3: 511-tap windowed-sinc FIR ({mode}), 1,024 ch x 2^20 samples fp32 noise, per GPU",
+                      "channels": channels, "n": n, "ntaps": ntaps, "sharding": "channels, no collective"}
+    return step, units, meta
+
+
+def make_mavg(torch, dev, ops, rank):
+    channels, n, pts = 1024, 1 << 20, 511
+    g = torch.Generator(device=dev).manual_seed(99 + rank)
+    x = torch.randn(channels, n, device=dev, generator=g)
+    y = torch.empty_like(x)
+
+    def step():
+        ops.moving_average(x, pts, out=y)
+
+    meta = dict(metric="moving_average_throughput", unit="GSamples/s", dtype="f32", bound="hbm", alg_per_unit=8.0,
+                alg_unit="bytes/sample", kernel="moving_average_kernel",
+                config={"workload": "511-point centred moving average, 1,024 ch x 2^20 samples, per GPU",
+                        "channels": channels, "n": n, "npoints": pts})
+    return step, channels * n, meta
+
+
+def make_iir(torch, dev, ops, rank, mode):
+    a, b = cheby_lp4_host()
+    if mode == "batch":
+        channels, n = 262144, 4096
+        wl = "C4a: 4-pole Chebyshev low-pass, 262,144 ch x 4,096 samples fp32 noise (batch-parallel), per GPU"
+    else:
+        channels, n = 1, 1 << 28
+        wl = "C4b: 4-pole Chebyshev low-pass, one 2^28-sample channel (block-parallel scan), per GPU"
+    g = torch.Generator(device=dev).manual_seed(777 + rank)
+    x = torch.randn(channels, n, device=dev, generator=g)
+    y = torch.empty_like(x)
+
+    def step():
+        ops.iir(x, a, b, mode=mode, out=y)
+
+    meta = dict(metric=f"iir_{mode}_throughput", unit="GSamples/s", dtype="f32", bound="hbm", alg_per_unit=8.0,
+                alg_unit="bytes/sample (4 B read + 4 B write)", kernel=f"iir_{mode}_kernel",
+                config={"workload": wl, "channels": channels, "n": n, "poles": 4})
+    return step, channels * n, meta
+
+
+def sinc_taps_host(cf, length):
+    """dsp::sinc (dsp.h:47-79), Blackman window: host-side design in double."""
+    from dsp_amd import design
+    return design.sinc(cf, length)
+
+
+def cheby_lp4_host():
+    """recursive::lowPassFilter<4>(0.1) coefficients (recursive_filters.h:153-157; KAT in SURVEY.md section 4)."""
+    from dsp_amd import design
+    return design.chebyshev(0.1, 4, highpass=False)
+
+
+# ----------------------------------------------------------------------------------------------
+def cpu_baseline(workload, seconds):
+    """Time the reference's CPU code on a bounded sample of the same workload (rank 0, N=1)."""
+    from oracle import available, load
+    kind = "reference" if available("ref") else "port"
+    lib = load("ref" if kind == "reference" else "fast")
+    rng = np.random.default_rng(1234)
+    t_end = time.perf_counter() + seconds
+    units = 0
+    t0 = time.perf_counter()
+    if workload == "fft":
+        chunk = 256
+        x = (rng.standard_normal((chunk, 4096)) + 1j * rng.standard_normal((chunk, 4096)))
+        while time.perf_counter() < t_end and units < 32768 * 4096:
+            lib.fft0(x)
+            units += chunk * 4096
+        unit, sample = "GSamples/s", f"{units // 4096} of 65,536 transforms, fft0 in complex double as the reference computes (fft.h:31-55)"
+    elif workload in ("fir_direct", "fir_os"):
+        h = sinc_taps_host(0.1, 511)
+        x = rng.standard_normal(1 << 16).astype(np.float32)
+        while time.perf_counter() < t_end:
+            lib.fir(x, h)
+            units += (x.size - 510) * (511 if workload == "fir_direct" else 1)
+        if workload == "fir_os":
+            units += 0
+        unit = "GMAC/s" if workload == "fir_direct" else "GSamples/s"
+        sample = f"SincFilter::apply (filter.h:123-140), float samples, 511 taps, repeated 2^16-sample slices of one channel"
+    elif workload == "mavg":
+        x = rng.standard_normal(1 << 22).astype(np.float32)
+        while time.perf_counter() < t_end:
+            lib.moving_average(x, 511)
+            units += x.size
+        unit, sample = "GSamples/s", "MovingAverageFilter{511} (filter.h:81-101), float, repeated 2^22-sample slices"
+    else:
+        from dsp_amd import design
+        a, b = design.chebyshev(0.1, 4)
+        x = rng.standard_normal(1 << 22).astype(np.float32)
+        while time.perf_counter() < t_end:
+            lib.iir(x, a, b)
+            units += x.size
+        unit, sample = "GSamples/s", "Coefficients<4>::operator()(SampleBuffer) (coefficients.h:88-130), float, repeated 2^22-sample slices"
+    dt = time.perf_counter() - t0
+    return {"value": units / dt / 1e9, "unit": unit, "cores": 1, "kind": kind, "sample": sample,
+            "seconds": round(dt, 2)}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with python -m torch.distributed.run --nproc-per-node N")
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (the product path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from dsp_amd import ops
+
+    if args.workload == "fft":
+        step, units, meta = make_fft(torch, dev, ops, rank)
+    elif args.workload in ("fir_direct", "fir_os"):
+        step, units, meta = make_fir(torch, dev, ops, rank, "direct" if args.workload == "fir_direct" else "overlap_save")
+    elif args.workload == "mavg":
+        step, units, meta = make_mavg(torch, dev, ops, rank)
+    else:
+        step, units, meta = make_iir(torch, dev, ops, rank, "batch" if args.workload == "iir_batch" else "scan")
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+
+    # The launches go to torch's current stream (ops passes its handle through the C ABI), so
+    # events recorded on that stream bracket exactly the kernels of the timed region.
+    stream = torch.cuda.current_stream(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    e0.record(stream)
+    for _ in range(args.steps):
+        step()
+    e1.record(stream)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = e0.elapsed_time(e1) / args.steps
+
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        total_units = units * world
+        value = total_units / elapsed / 1e9
+        launch_s = kernel_ms * 1e-3
+        if meta["bound"] == "hbm":
+            achieved = units * meta["alg_per_unit"] / launch_s / 1e9
+            roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS}
+        else:
+            achieved = units * meta["alg_per_unit"] / launch_s / 1e12
+            roof = {"bound": "mfma", "achieved": achieved, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": achieved / FP32_PEAK_TFLOPS}
+        roof.update({"traffic": measured_traffic(args.workload), "kernel": meta["kernel"],
+                     "launch_ms": kernel_ms, "algorithmic": meta["alg_unit"]})
+        line = {"metric": meta["metric"], "value": value, "unit": meta["unit"], "n_gpus": world, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+                "scaling": "weak", "vs_baseline": None, "dtype": meta["dtype"], "data": "synthetic",
+                "config": meta["config"], "roofline": roof}
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_seconds)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def measured_traffic(workload):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic.json), or None."""
+    p = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(p):
+        return None
+    try:
+        return json.load(open(p)).get(workload, {}).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
+if __name__ == "__main__":
+    main()

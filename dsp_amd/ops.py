@@ -91,24 +91,24 @@ _MODES = {"auto": capi.CONV_AUTO, "direct": capi.CONV_DIRECT, "time": capi.CONV_
           "overlap_save": capi.CONV_OVERLAP_SAVE, "frequency": capi.CONV_OVERLAP_SAVE}
 
 
-def convolve(x, taps, mode: str = "auto"):
+def convolve(x, taps, mode: str = "auto", out=None):
     """Causal FIR, first len(taps)-1 outputs zero.  x: [n] or [channels, n] fp32.  filter.h:123-140."""
     x, px, mem = _prep(x, np.float32, "float32")
     taps = np.ascontiguousarray(taps, dtype=np.float32)  # the designers produce double; the device runs fp32
     n = x.shape[-1]
     channels = int(np.prod(x.shape[:-1])) if x.ndim > 1 else 1
-    y = _empty_like(x, tuple(x.shape), np.float32, "float32")
+    y = out if out is not None else _empty_like(x, tuple(x.shape), np.float32, "float32")
     capi.check(capi.lib().dsp_gpu_convolve(px, _ptr(y), channels, n, taps.ctypes.data, taps.size, _MODES[mode], mem,
                                            _stream_of(x)))
     return y
 
 
-def moving_average(x, npoints: int):
+def moving_average(x, npoints: int, out=None):
     """Centred moving average, zero edges.  filter.h:81-101."""
     x, px, mem = _prep(x, np.float32, "float32")
     n = x.shape[-1]
     channels = int(np.prod(x.shape[:-1])) if x.ndim > 1 else 1
-    y = _empty_like(x, tuple(x.shape), np.float32, "float32")
+    y = out if out is not None else _empty_like(x, tuple(x.shape), np.float32, "float32")
     capi.check(capi.lib().dsp_gpu_moving_average(px, _ptr(y), channels, n, int(npoints), mem, _stream_of(x)))
     return y
 
@@ -116,7 +116,7 @@ def moving_average(x, npoints: int):
 _IIR_MODES = {"auto": capi.IIR_AUTO, "batch": capi.IIR_BATCH, "scan": capi.IIR_SCAN}
 
 
-def iir(x, a, b, c0: float = 1.0, d0: float = 0.0, state=None, mode: str = "auto"):
+def iir(x, a, b, c0: float = 1.0, d0: float = 0.0, state=None, mode: str = "auto", out=None):
     """IIR recursion with feedback ADDED (coefficients.h:106-130).  state: [channels, 2*poles] fp32, updated in place."""
     x, px, mem = _prep(x, np.float32, "float32")
     a = np.ascontiguousarray(a, dtype=np.float64)
@@ -126,7 +126,7 @@ def iir(x, a, b, c0: float = 1.0, d0: float = 0.0, state=None, mode: str = "auto
     poles = a.size - 1
     n = x.shape[-1]
     channels = int(np.prod(x.shape[:-1])) if x.ndim > 1 else 1
-    y = _empty_like(x, tuple(x.shape), np.float32, "float32")
+    y = out if out is not None else _empty_like(x, tuple(x.shape), np.float32, "float32")
     pstate = None
     if state is not None:
         if _is_torch(state) != _is_torch(x):

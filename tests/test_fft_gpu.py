@@ -1,0 +1,188 @@
+"""GPU parity of the batched FFT (dsp_gpu_fft_batch / dsp_gpu_fft_real_batch) through the C ABI.
+
+Tolerance (BASELINE.json north_star): relative L2 error <= 1e-5 * log2(N) against the reference's
+double-precision result on the same float-exact inputs.
+"""
+import numpy as np
+import pytest
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+def budget(log2n):
+    return 1e-5 * max(log2n, 1)
+
+
+@pytest.fixture(scope="module")
+def ops(dev):
+    from dsp_amd import ops as _ops
+    return _ops
+
+
+@pytest.mark.parametrize("n", [2, 8, 64, 1024, 4096])
+def test_golden_vectors(ops, dev, golden, n):
+    import torch
+    x = golden[f"fft_{n}_in"]
+    k = n.bit_length() - 1
+    for inv, key in ((False, "fwd"), (True, "inv")):
+        want = golden[f"fft_{n}_{key}"]
+        got_d = ops.fft0(torch.from_numpy(x).to(dev), inv).cpu().numpy()
+        got_h = ops.fft0(x, inv)  # host pointers, staged by the library
+        assert rel_l2(got_d, want) <= budget(k)
+        assert np.array_equal(got_d, got_h)
+
+
+def test_kat_sign_and_scaling(ops, dev, golden):
+    import torch
+    x = golden["kat_fft8_in"].astype(np.complex64)
+    fwd = ops.fft0(torch.from_numpy(x).to(dev))
+    assert np.allclose(fwd.cpu().numpy(), golden["kat_fft8_fwd"], atol=1e-5)
+    assert fwd.cpu().numpy()[1].imag < 0  # e^{+i} FORWARD: conjugate of numpy's forward (fft.h:22-29)
+    back = ops.fft0(fwd, inverse=True).cpu().numpy()
+    assert np.allclose(back, 8 * x, atol=1e-4)  # neither direction normalises
+
+
+@pytest.mark.parametrize("log2n", list(range(1, 15)) + [16, 17, 18, 20])
+def test_oracle_parity(ops, dev, orc, log2n):
+    import torch
+    rng = np.random.default_rng(1000 + log2n)
+    n = 1 << log2n
+    batch = 5 if log2n <= 12 else (2 if log2n <= 16 else 1)
+    x = (rng.standard_normal((batch, n)) + 1j * rng.standard_normal((batch, n))).astype(np.complex64)
+    xd = torch.from_numpy(x).to(dev)
+    for inv in (False, True):
+        want = orc.fft0(x.astype(np.complex128), inv)
+        got = ops.fft0(xd, inv).cpu().numpy()
+        assert rel_l2(got, want) <= budget(log2n), (log2n, inv)
+    assert np.array_equal(xd.cpu().numpy(), x)  # input untouched (fft.h:32: `in` is read only)
+
+
+@pytest.mark.parametrize("log2n,batch", [(4, 1), (4, 255), (4, 257), (6, 63), (8, 17), (11, 3), (12, 1), (3, 1000), (1, 7)])
+def test_ragged_batches(ops, dev, orc, log2n, batch):
+    """Batches that do not fill the last workgroup (several small transforms share one)."""
+    import torch
+    rng = np.random.default_rng(batch * 13 + log2n)
+    n = 1 << log2n
+    x = (rng.standard_normal((batch, n)) + 1j * rng.standard_normal((batch, n))).astype(np.complex64)
+    guard = torch.full((batch + 2, n), 7 + 7j, dtype=torch.complex64, device=dev)
+    out = guard[1:-1]
+    ops.fft0(torch.from_numpy(x).to(dev), out=out)
+    assert rel_l2(out.cpu().numpy(), orc.fft0(x.astype(np.complex128))) <= budget(log2n)
+    g = guard.cpu().numpy()
+    assert (g[0] == 7 + 7j).all() and (g[-1] == 7 + 7j).all()  # nothing written outside the batch
+
+
+@pytest.mark.parametrize("log2n", [5, 12, 14, 18])
+def test_in_place(ops, dev, orc, log2n):
+    import torch
+    rng = np.random.default_rng(log2n)
+    n = 1 << log2n
+    x = (rng.standard_normal((3, n)) + 1j * rng.standard_normal((3, n))).astype(np.complex64)
+    xd = torch.from_numpy(x).to(dev)
+    ops.fft0(xd, out=xd)
+    assert rel_l2(xd.cpu().numpy(), orc.fft0(x.astype(np.complex128))) <= budget(log2n)
+
+
+@pytest.mark.parametrize("tag,nf", [("impulse", 64), ("rect", 128), ("sinc", 128), ("pad", 300)])
+def test_real_wrapper_golden(ops, dev, golden, tag, nf):
+    """dsp::fft (fft.h:57-83) on the eval/fft_pairs recipes, incl. zero padding 300 -> 512."""
+    import torch
+    x = golden[f"pairs_{tag}_in"].astype(np.float32)
+    want = golden[f"pairs_{tag}_out"]
+    got = ops.fft(torch.from_numpy(x).to(dev), nf).cpu().numpy()
+    assert got.shape == want.shape
+    k = want.size.bit_length() - 1
+    # the fixture input is double; compare against the oracle on the fp32-rounded input too
+    assert rel_l2(got, want) <= budget(k) + 2e-7
+    assert np.array_equal(got, ops.fft(x, nf))
+
+
+@pytest.mark.parametrize("n_in,nf,batch", [(100, 128, 4), (300, 300, 3), (4096, 4096, 2), (5000, 4096, 2), (3, 2, 5),
+                                           (20000, 20000, 2), (70000, 1 << 17, 1)])
+def test_real_wrapper_oracle(ops, dev, orc, n_in, nf, batch):
+    import torch
+    rng = np.random.default_rng(n_in + nf)
+    x = rng.standard_normal((batch, n_in)).astype(np.float32)
+    xd = torch.from_numpy(x).to(dev)
+    for inv in (False, True):
+        want = np.stack([orc.fft_real(x[b].astype(np.float64), nf, inv) for b in range(batch)])
+        got = ops.fft(xd, nf, inverse=inv).cpu().numpy()
+        k = want.shape[-1].bit_length() - 1
+        assert rel_l2(got, want) <= budget(k)
+        got_s = ops.fft(xd, nf, inverse=inv, shift=True).cpu().numpy()
+        want_s = np.stack([orc.shift(w) for w in want])
+        assert rel_l2(got_s, want_s) <= budget(k)
+
+
+def test_chain_impulse_response_spectrum(ops, dev, golden):
+    """eval/recursive_filters/main.cpp:104-121: filter response -> 1024-point fft (the fft half)."""
+    import torch
+    for tag in ("lp2", "pk"):
+        resp = golden[f"chain_{tag}_response"].astype(np.float32)
+        got = ops.fft(torch.from_numpy(resp).to(dev), 1024).cpu().numpy()
+        assert rel_l2(got, golden[f"chain_{tag}_fft"]) <= budget(10)
+
+
+def test_c2_full_size_properties(ops, dev):
+    """BASELINE config 2 at full size (65,536 x 4096): size-independent properties."""
+    import torch
+    g = torch.Generator(device=dev).manual_seed(1234)
+    B, N = 65536, 4096
+    x = torch.view_as_complex(torch.randn(B, N, 2, device=dev, generator=g))
+    X = ops.fft0(x)
+    # Parseval: sum |X|^2 = N sum |x|^2, per transform
+    ex = (x.real.double() ** 2 + x.imag.double() ** 2).sum(dim=1)
+    eX = (X.real.double() ** 2 + X.imag.double() ** 2).sum(dim=1)
+    assert float(((eX / (N * ex)) - 1).abs().max()) < 1e-5
+    # round trip: INVERSE(FORWARD(x)) = N x
+    back = ops.fft0(X, inverse=True)
+    num = torch.linalg.vector_norm((back / N - x).reshape(-1).view(torch.float32).double())
+    den = torch.linalg.vector_norm(x.reshape(-1).view(torch.float32).double())
+    assert float(num / den) <= 2 * budget(12)
+    # linearity on a slice: F(a x + b y) = a F(x) + b F(y)
+    y = torch.roll(x[:256], 1, 0)
+    lhs = ops.fft0(2.5 * x[:256] - 0.5j * y)
+    rhs = 2.5 * X[:256] - 0.5j * ops.fft0(y)
+    assert float(torch.linalg.vector_norm(lhs - rhs) / torch.linalg.vector_norm(rhs)) <= 2 * budget(12)
+    # exact-bin tones: row r holds exp(-2 pi i k n / N) with k = r mod N  -> FORWARD peak N at bin k
+    r = torch.arange(512, device=dev)
+    n = torch.arange(N, device=dev)
+    ph = (-(r[:, None] * n[None, :]) % N).double() * (2 * np.pi / N)
+    tone = torch.complex(torch.cos(ph), torch.sin(ph)).to(torch.complex64)
+    T = ops.fft0(tone)
+    peak = T.abs().argmax(dim=1)
+    # FORWARD is e^{+i}: x = e^{-i 2 pi k n/N} peaks at bin k
+    assert torch.equal(peak, r)
+    assert float((T.abs().max(dim=1).values - N).abs().max()) < 0.05
+
+
+def test_large_single_transform_round_trip(ops, dev):
+    import torch
+    g = torch.Generator(device=dev).manual_seed(2030)
+    n = 1 << 24
+    x = torch.view_as_complex(torch.randn(1, n, 2, device=dev, generator=g))
+    X = ops.fft0(x)
+    back = ops.fft0(X, inverse=True) / n
+    err = torch.linalg.vector_norm((back - x).view(torch.float32).double()) / torch.linalg.vector_norm(x.view(torch.float32).double())
+    assert float(err) <= 2 * budget(24)
+    # one exact-bin tone on top of the noise floor shows up where the e^{+i} convention puts it
+    k = 1234567
+    idx = torch.arange(n, device=dev, dtype=torch.int64)
+    ph = ((idx * k) % n).double() * (2 * np.pi / n)
+    tone = torch.complex(torch.cos(ph), -torch.sin(ph)).to(torch.complex64)[None]
+    T = ops.fft0(tone)
+    assert int(T.abs().argmax()) == k
+    assert abs(float(T.abs().max()) / n - 1) < 1e-3
+
+
+def test_errors(ops, dev):
+    import torch
+    from dsp_amd import capi
+    with pytest.raises(capi.DspGpuError):
+        ops.fft0(torch.zeros(3, 100, dtype=torch.complex64, device=dev))  # not a power of two
+    with pytest.raises(capi.DspGpuError):
+        ops.fft0(torch.zeros(3, 64, dtype=torch.complex128, device=dev))  # fp32 only
+    with pytest.raises(capi.DspGpuError):
+        ops.fft0(torch.zeros(1, 64, dtype=torch.complex64))  # CPU torch tensor: pass numpy for host memory
