@@ -286,7 +286,7 @@ int dsp_gpu_moving_average(const float *x, float *y, size_t channels, size_t n, 
 }
 
 int dsp_gpu_iir(const float *x, float *y, size_t channels, size_t n, const double *a, const double *b, int poles,
-                double c0, double d0, float *state, int mode, int mem, void *stream) {
+                double c0, double d0, double *state, int mode, int mem, void *stream) {
     if (!x || !y || !a || !b) return fail(DSP_GPU_EINVAL, "dsp_gpu_iir: null buffer");
     if (poles < 1 || poles > 8) return fail(DSP_GPU_EINVAL, "dsp_gpu_iir: poles %d outside [1,8]", poles);
     if (mode != DSP_GPU_IIR_AUTO && mode != DSP_GPU_IIR_BATCH && mode != DSP_GPU_IIR_SCAN)
@@ -296,20 +296,22 @@ int dsp_gpu_iir(const float *x, float *y, size_t channels, size_t n, const doubl
     IirCoef co{};
     co.poles = poles;
     for (int i = 0; i <= poles; ++i) {
-        co.a[i] = static_cast<float>(a[i]);
-        co.b[i] = i == 0 ? 0.0f : static_cast<float>(b[i]);  // coefficients.h:93 requires b[0] == 0
+        co.a[i] = a[i];
+        co.b[i] = i == 0 ? 0.0 : b[i];  // coefficients.h:93 requires b[0] == 0
         if (!std::isfinite(co.a[i]) || !std::isfinite(co.b[i])) return fail(DSP_GPU_EINVAL, "dsp_gpu_iir: non-finite coefficient");
     }
-    co.c0 = static_cast<float>(c0);
-    co.d0 = static_cast<float>(d0);
-    if (mode == DSP_GPU_IIR_AUTO)  // few long channels cannot fill the chip one thread per channel
+    co.c0 = c0;
+    co.d0 = d0;
+    if (!std::isfinite(c0) || !std::isfinite(d0)) return fail(DSP_GPU_EINVAL, "dsp_gpu_iir: non-finite c0/d0");
+    const bool auto_mode = mode == DSP_GPU_IIR_AUTO;
+    if (auto_mode)  // few long channels cannot fill the chip one thread per channel
         mode = (channels < 8192 && n >= 65536) ? DSP_GPU_IIR_SCAN : DSP_GPU_IIR_BATCH;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t bytes = channels * n * sizeof(float);
-    const size_t state_bytes = channels * 2 * static_cast<size_t>(poles) * sizeof(float);
+    const size_t state_bytes = channels * 2 * static_cast<size_t>(poles) * sizeof(double);
     const float *dx = x;
     float *dy = y;
-    float *dstate = state;
+    double *dstate = state;
     HostStage hs;
     if (mem == DSP_GPU_MEM_HOST) {
         if (int rc = stage_in(x, bytes, bytes, s, &hs)) return rc;
@@ -318,12 +320,14 @@ int dsp_gpu_iir(const float *x, float *y, size_t channels, size_t n, const doubl
         if (state) {
             void *p = nullptr;
             if (int rc = workspace(WS_STATE, state_bytes, &p)) return rc;
-            dstate = static_cast<float *>(p);
+            dstate = static_cast<double *>(p);
             DSPGPU_HIP(hipMemcpyAsync(dstate, state, state_bytes, hipMemcpyHostToDevice, s));
         }
     }
     int rc = mode == DSP_GPU_IIR_SCAN ? launch_iir_scan(dx, dy, channels, n, co, dstate, s)
                                       : launch_iir_batch(dx, dy, channels, n, co, dstate, s);
+    if (rc == DSP_GPU_EUNSUPPORTED && auto_mode && mode == DSP_GPU_IIR_SCAN)  // ill-conditioned for the scan
+        rc = launch_iir_batch(dx, dy, channels, n, co, dstate, s);
     if (rc) return rc;
     if (mem == DSP_GPU_MEM_HOST) {
         if (state) DSPGPU_HIP(hipMemcpyAsync(state, dstate, state_bytes, hipMemcpyDeviceToHost, s));

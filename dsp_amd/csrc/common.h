@@ -38,7 +38,9 @@ inline int check_launch(const char *what) {
 
 // Device workspace owned by the library (one growing buffer per device and slot).
 // Slots keep independent users (host staging in/out, FFT scratch, ...) from aliasing.
-enum WorkspaceSlot { WS_STAGE_IN = 0, WS_STAGE_OUT, WS_SCRATCH_A, WS_SCRATCH_B, WS_STATE, WS_SLOTS };
+enum WorkspaceSlot {
+    WS_STAGE_IN = 0, WS_STAGE_OUT, WS_SCRATCH_A, WS_SCRATCH_B, WS_STATE, WS_STATE_SNAP, WS_IIR_TABLE, WS_SLOTS
+};
 int workspace(WorkspaceSlot slot, size_t bytes, void **ptr);
 void release_all_workspaces();
 
@@ -53,15 +55,15 @@ int launch_fir_overlap_save(const float *x, float *y, size_t channels, size_t n,
 int launch_fir_spectrum(const float *d_taps, int ntaps, float2 *d_hspec, hipStream_t s);
 int launch_moving_average(const float *x, float *y, size_t channels, size_t n, int npoints, hipStream_t s);
 
-struct IirCoef {  // fp32 device view of a Coefficients<Poles> (coefficients.h:7-15)
-    float a[9];
-    float b[9];
-    float c0, d0;
+struct IirCoef {  // a Coefficients<Poles> without its history (coefficients.h:7-15), double as in the reference
+    double a[9];
+    double b[9];
+    double c0, d0;
     int poles;
 };
-int launch_iir_batch(const float *x, float *y, size_t channels, size_t n, const IirCoef &co, float *state,
+int launch_iir_batch(const float *x, float *y, size_t channels, size_t n, const IirCoef &co, double *state,
                      hipStream_t s);
-int launch_iir_scan(const float *x, float *y, size_t channels, size_t n, const IirCoef &co, float *state,
+int launch_iir_scan(const float *x, float *y, size_t channels, size_t n, const IirCoef &co, double *state,
                     hipStream_t s);
 
 }  // namespace dspgpu

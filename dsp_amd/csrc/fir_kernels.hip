@@ -1,0 +1,307 @@
+// fir_kernels.hip -- FIR convolution and centred moving average for gfx950 (MI355X).
+//
+// Stands in for dsp::filter::SincFilter<>::apply (reference filter.h:123-140), dsp::convolve
+// (convolution.h:8-29, incl. the Frequency branch the reference only declares) and
+// dsp::filter::MovingAverageFilter::apply (filter.h:81-101).
+//
+// Kernels
+//   fir_direct_kernel        y[j] = sum_i h[i] x[j-i] as a Toeplitz product on the fp32 matrix
+//                            cores (v_mfma_f32_16x16x4_f32: exact fp32 fma chains at the fp32
+//                            vector rate).  A 16x16 output tile holds 256 consecutive outputs
+//                            y[j0 + 16c + r]; with m = r - i = 16p + t the sum becomes
+//                              D[r][c] = sum_p sum_t h[r - 16p - t] * x[j0 + 16(c+p) + t]
+//                            i.e. one 16x16 Toeplitz block of taps times the data block shifted
+//                            by p columns.  Both operands come from LDS as one ds_read_b128 per
+//                            four MFMAs; a wave keeps 4 tiles (independent accumulators) going.
+//   fir_overlap_save_kernel  4096-point overlap-save: two real blocks ride one complex FFT
+//                            (a + i b; valid because the taps are real), multiplied by the cached
+//                            tap spectrum, inverse FFT, real/imag parts stored.  One workgroup per
+//                            block pair, the transform never leaves registers + LDS.
+//   moving_average_kernel    windows summed from 16-sample partial sums held in LDS (no running
+//                            sum along the signal, so no accumulated drift).
+#include <algorithm>
+
+#include "common.h"
+#include "fft_lds_core.h"
+
+namespace dspgpu {
+namespace {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+// ---------------------------------------------------------------------------------------------
+// direct FIR on fp32 MFMA
+// ---------------------------------------------------------------------------------------------
+constexpr int kFirThreads = 256;
+constexpr int kFirWaves = kFirThreads / 64;
+constexpr int kFirTile = 256;      // outputs per 16x16 tile
+constexpr int kFirAcc = 4;         // tiles (accumulators) per wave per pass
+constexpr int kFirPasses = 2;
+constexpr int kFirSeg = 16;        // Toeplitz blocks (of 16 taps) per accumulation segment
+constexpr int kFirOutPerWg = kFirWaves * kFirAcc * kFirTile * kFirPasses;  // 8192 outputs
+
+// LDS: float xs[hist + kFirOutPerWg] followed by 4 shifted, reversed, zero padded copies of the
+// taps, each taps_len = 16*Q + 16 floats:  copy s holds As[w] = h[16Q - s - w].
+template <bool ALIGNED>
+__global__ __launch_bounds__(kFirThreads) void fir_direct_kernel(const float *__restrict__ x, float *__restrict__ y,
+                                                                  size_t n, const float *__restrict__ taps, int ntaps,
+                                                                  int Q) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int hist = 16 * (Q - 1);
+    const int xs_len = hist + kFirOutPerWg;
+    const int taps_len = 16 * Q + 16;
+    float *xs = smem;
+    float *as = smem + xs_len;
+
+    const int tid = threadIdx.x;
+    const size_t ch = blockIdx.y;
+    const long long chunk0 = static_cast<long long>(blockIdx.x) * kFirOutPerWg;
+    const float *xc = x + ch * n;
+    float *yc = y + ch * n;
+    const long long nn = static_cast<long long>(n);
+
+    // taps: 4 shifted reversed copies
+    for (int i = tid; i < 4 * taps_len; i += kFirThreads) {
+        const int s = i / taps_len, w = i - s * taps_len;
+        const int idx = 16 * Q - s - w;
+        as[i] = (idx >= 0 && idx < ntaps) ? taps[idx] : 0.0f;
+    }
+    // input segment [chunk0 - hist, chunk0 + OutPerWg), zeros outside the channel
+    const long long seg0 = chunk0 - hist;
+    for (int u = tid * 4; u < xs_len; u += kFirThreads * 4) {
+        const long long g = seg0 + u;
+        float4 v;
+        if (ALIGNED && g >= 0 && g + 3 < nn) {
+            v = *reinterpret_cast<const float4 *>(xc + g);
+        } else {
+            v.x = (g >= 0 && g < nn) ? xc[g] : 0.0f;
+            v.y = (g + 1 >= 0 && g + 1 < nn) ? xc[g + 1] : 0.0f;
+            v.z = (g + 2 >= 0 && g + 2 < nn) ? xc[g + 2] : 0.0f;
+            v.w = (g + 3 >= 0 && g + 3 < nn) ? xc[g + 3] : 0.0f;
+        }
+        *reinterpret_cast<float4 *>(xs + u) = v;
+    }
+    __syncthreads();
+
+    const int lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, kq = lane >> 4;  // r: A row / B column, kq: k slot
+    const int s = (4 - (r & 3)) & 3;
+    const float *a_ptr = as + s * taps_len + (16 * Q - s - r + 4 * kq);  // minus 16 q per step
+    const int order = ntaps - 1;
+
+#pragma unroll 1
+    for (int pass = 0; pass < kFirPasses; ++pass) {
+        const int tile0 = (pass * kFirWaves + wave) * kFirAcc;  // first of this wave's tiles in the chunk
+        if (chunk0 + static_cast<long long>(tile0) * kFirTile >= nn) break;  // wave-uniform
+        const float *b_ptr = xs + hist + tile0 * kFirTile + 16 * r + 4 * kq;
+        // The taps are summed in segments of kFirSeg blocks (256 taps) with a fresh accumulator each,
+        // so the fp32 rounding of a long filter grows like a blocked sum, not like one long chain.
+        f32x4 acc[kFirAcc];
+#pragma unroll
+        for (int t = 0; t < kFirAcc; ++t) acc[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll 1
+        for (int q0 = 0; q0 < Q; q0 += kFirSeg) {
+            const int q1 = q0 + kFirSeg < Q ? q0 + kFirSeg : Q;
+            f32x4 seg[kFirAcc];
+#pragma unroll
+            for (int t = 0; t < kFirAcc; ++t) seg[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            for (int q = q0; q < q1; ++q) {
+                const f32x4 a4 = *reinterpret_cast<const f32x4 *>(a_ptr - 16 * q);
+                f32x4 b4[kFirAcc];
+#pragma unroll
+                for (int t = 0; t < kFirAcc; ++t)
+                    b4[t] = *reinterpret_cast<const f32x4 *>(b_ptr + t * kFirTile - 16 * q);
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+                    for (int t = 0; t < kFirAcc; ++t)
+                        seg[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[kk], b4[t][kk], seg[t], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < kFirAcc; ++t) acc[t] += seg[t];
+        }
+        // D: column = lane & 15, rows 4*(lane >> 4) + i  ->  y[j0 + 16*col + 4*(lane>>4) + i]
+#pragma unroll
+        for (int t = 0; t < kFirAcc; ++t) {
+            const long long j = chunk0 + static_cast<long long>(tile0 + t) * kFirTile + 16 * r + 4 * kq;
+            if (j >= nn) continue;
+            float o[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = (j + i >= order) ? acc[t][i] : 0.0f;  // filter.h:133: first M outputs stay 0
+            if (ALIGNED && j + 3 < nn) {
+                *reinterpret_cast<float4 *>(yc + j) = make_float4(o[0], o[1], o[2], o[3]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (j + i < nn) yc[j + i] = o[i];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// overlap-save FIR
+// ---------------------------------------------------------------------------------------------
+constexpr int kOsN = 4096;
+constexpr int kOsLog2N = 12;
+
+// hspec: FORWARD spectrum of the zero padded taps (unscaled).  Block b of a channel produces
+// outputs [order + b*L, order + (b+1)*L) from inputs [b*L, b*L + 4096), L = 4096 - order.
+__global__ __launch_bounds__(kThreads) void fir_overlap_save_kernel(const float *__restrict__ x, float *__restrict__ y,
+                                                                    size_t n, const c32 *__restrict__ hspec, int ntaps,
+                                                                    unsigned pairs_per_channel) {
+    __shared__ c32 lds[kLdsElems];
+    const int tid = threadIdx.x;
+    const size_t ch = blockIdx.x / pairs_per_channel;
+    const unsigned pair = blockIdx.x % pairs_per_channel;
+    const long long order = ntaps - 1;
+    const long long L = kOsN - order;
+    const long long nn = static_cast<long long>(n);
+    const float *xc = x + ch * n;
+    float *yc = y + ch * n;
+    const long long in_a = static_cast<long long>(2 * pair) * L, in_b = in_a + L;
+
+    c32 r[kPoints];
+#pragma unroll
+    for (int m = 0; m < kPoints; ++m) {
+        const long long ia = in_a + tid + kThreads * m, ib = in_b + tid + kThreads * m;
+        r[m] = make_float2(ia < nn ? xc[ia] : 0.0f, ib < nn ? xc[ib] : 0.0f);
+    }
+    fft_passes<kOsLog2N, +1>(r, lds, tid, 0);
+    constexpr float scale = 1.0f / kOsN;
+#pragma unroll
+    for (int m = 0; m < kPoints; ++m) {
+        const c32 h = hspec[tid + kThreads * m];
+        const c32 v = cmul(r[m], h);
+        r[m] = make_float2(v.x * scale, v.y * scale);
+    }
+    __syncthreads();  // the forward passes' last LDS image has been read by everyone
+    fft_passes<kOsLog2N, -1>(r, lds, tid, 0);
+
+    if (pair == 0)  // filter.h:126,133: the first `order` outputs of the channel stay zero
+        for (long long j = tid; j < order && j < nn; j += kThreads) yc[j] = 0.0f;
+#pragma unroll
+    for (int m = 0; m < kPoints; ++m) {
+        const long long k = tid + kThreads * m;
+        if (k < order) continue;  // wrapped (circular) part of the block
+        const long long ja = in_a + k, jb = in_b + k;
+        if (ja < nn) yc[ja] = r[m].x;
+        if (jb < nn) yc[jb] = r[m].y;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// centred moving average
+// ---------------------------------------------------------------------------------------------
+constexpr int kMaPer = 16;                       // outputs per thread
+constexpr int kMaTile = kThreads * kMaPer;       // 4096 outputs per workgroup
+DSP_DEV int ma_pad(int i) { return i + ((i >> 4) << 2); }  // 4 pad floats per 16: conflict-free ds_read_b128
+
+// The reference's running sum (filter.h:88-98) starts from x[0..P) and then adds x[i+mid], drops
+// x[i-mid-1] with mid = P/2.  Algebraically that is
+//     y[i] = (sum_{k=i-mid}^{i+mid} x[k]  -  (P even ? x[P] : 0)) / P      for mid <= i < n-mid
+// (for odd P the plain centred mean; for even P -- reachable through numPoints(), which does not
+// re-force odd, filter.h:72-74 -- a 2*mid+1 window minus the constant x[P]).  Reproduced as is.
+// LDS: xs[ma_pad(span16)] then chunk sums cs[span16/16].
+__global__ __launch_bounds__(kThreads) void moving_average_kernel(const float *__restrict__ x, float *__restrict__ y,
+                                                                  size_t n, int npoints, int span16) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *xs = smem;
+    float *cs = smem + ma_pad(span16);
+    const int tid = threadIdx.x;
+    const size_t ch = blockIdx.y;
+    const long long nn = static_cast<long long>(n);
+    const long long mid = npoints / 2;
+    const int window = 2 * static_cast<int>(mid) + 1;
+    const long long out0 = static_cast<long long>(blockIdx.x) * kMaTile;  // first output of the tile
+    const long long seg0 = out0 - mid;                                    // xs[0] = x[seg0]
+    const float *xc = x + ch * n;
+    float *yc = y + ch * n;
+    const float corr = ((npoints & 1) == 0 && npoints < nn) ? xc[npoints] : 0.0f;
+
+    for (int u = tid; u < span16; u += kThreads) {
+        const long long g = seg0 + u;
+        xs[ma_pad(u)] = (g >= 0 && g < nn) ? xc[g] : 0.0f;
+    }
+    __syncthreads();
+    for (int c = tid; c < span16 / 16; c += kThreads) {
+        float sum = 0.0f;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const float4 p = *reinterpret_cast<const float4 *>(xs + ma_pad(16 * c + 4 * v));
+            sum += (p.x + p.y) + (p.z + p.w);
+        }
+        cs[c] = sum;
+    }
+    __syncthreads();
+
+    // thread t: outputs out0 + 16 t + [0,16); window of the first = xs[16 t .. 16 t + window)
+    const int whole = window >> 4, rest = window & 15;
+    float sum = 0.0f;
+    for (int k = 0; k < whole; ++k) sum += cs[tid + k];
+    for (int i = 0; i < rest; ++i) sum += xs[ma_pad(16 * (tid + whole) + i)];
+    const float inv = 1.0f / static_cast<float>(npoints);
+    const long long hi = (nn - mid > mid + 1) ? nn - mid : mid + 1;  // out[mid] is always written (filter.h:93)
+#pragma unroll
+    for (int i = 0; i < kMaPer; ++i) {
+        const long long j = out0 + 16 * tid + i;
+        if (j < nn) yc[j] = (j >= mid && j < hi) ? (sum - corr) * inv : 0.0f;
+        sum += xs[ma_pad(16 * tid + i + window)] - xs[ma_pad(16 * tid + i)];
+    }
+}
+
+}  // namespace
+
+int launch_fir_direct(const float *x, float *y, size_t channels, size_t n, const float *d_taps, int ntaps,
+                      hipStream_t s) {
+    const int order = ntaps - 1;
+    const int Q = (order + 15) / 16 + 1;
+    const size_t lds_bytes = (static_cast<size_t>(16 * (Q - 1) + kFirOutPerWg) + 4u * (16 * Q + 16)) * sizeof(float);
+    const size_t blocks = (n + kFirOutPerWg - 1) / kFirOutPerWg;
+    if (channels > 65535) return fail(DSP_GPU_EUNSUPPORTED, "direct FIR: more than 65535 channels per call");
+    const bool aligned = (n % 4 == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0) && (reinterpret_cast<uintptr_t>(y) % 16 == 0);
+    auto kern = aligned ? fir_direct_kernel<true> : fir_direct_kernel<false>;
+    if (lds_bytes > 64 * 1024)
+        DSPGPU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       static_cast<int>(lds_bytes)));
+    hipLaunchKernelGGL(kern, dim3(blocks, channels), dim3(kFirThreads), lds_bytes, s, x, y, n, d_taps, ntaps, Q);
+    return check_launch("fir_direct_kernel");
+}
+
+int launch_fir_spectrum(const float *d_taps, int ntaps, float2 *d_hspec, hipStream_t s) {
+    // FORWARD transform of the taps zero padded to 4096 points (the real-input wrapper does the padding)
+    return launch_fft_real_batch(d_taps, static_cast<size_t>(ntaps), static_cast<size_t>(ntaps), d_hspec, kOsLog2N, 1,
+                                 DSP_GPU_FORWARD, 0, s);
+}
+
+int launch_fir_overlap_save(const float *x, float *y, size_t channels, size_t n, const float2 *d_hspec, int ntaps,
+                            hipStream_t s) {
+    const long long order = ntaps - 1;
+    const long long L = kOsN - order;
+    const long long valid = static_cast<long long>(n) > order ? static_cast<long long>(n) - order : 0;
+    long long nblocks = (valid + L - 1) / L;
+    if (nblocks < 1) nblocks = 1;  // block 0 also zero-fills y[0, order)
+    const unsigned pairs = static_cast<unsigned>((nblocks + 1) / 2);
+    const size_t grid = channels * pairs;
+    if (grid > 0x7fffffffull) return fail(DSP_GPU_EUNSUPPORTED, "overlap-save FIR: grid too large");
+    hipLaunchKernelGGL(fir_overlap_save_kernel, dim3(static_cast<unsigned>(grid)), dim3(kThreads), 0, s, x, y, n, d_hspec,
+                       ntaps, pairs);
+    return check_launch("fir_overlap_save_kernel");
+}
+
+int launch_moving_average(const float *x, float *y, size_t channels, size_t n, int npoints, hipStream_t s) {
+    if (npoints > 16384) return fail(DSP_GPU_EUNSUPPORTED, "moving average: npoints %d > 16384", npoints);
+    if (channels > 65535) return fail(DSP_GPU_EUNSUPPORTED, "moving average: more than 65535 channels per call");
+    const int span16 = ((kMaTile + npoints + 1 + 15) / 16) * 16;  // samples staged per tile (incl. the slide-out reads)
+    const size_t lds_bytes = (static_cast<size_t>(span16 + (span16 / 16) * 4 + 8) + span16 / 16 + 8) * sizeof(float);
+    const size_t blocks = (n + kMaTile - 1) / kMaTile;
+    if (lds_bytes > 64 * 1024)
+        DSPGPU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(moving_average_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes)));
+    hipLaunchKernelGGL(moving_average_kernel, dim3(blocks, channels), dim3(kThreads), lds_bytes, s, x, y, n, npoints,
+                       span16);
+    return check_launch("moving_average_kernel");
+}
+
+}  // namespace dspgpu

@@ -117,7 +117,10 @@ _IIR_MODES = {"auto": capi.IIR_AUTO, "batch": capi.IIR_BATCH, "scan": capi.IIR_S
 
 
 def iir(x, a, b, c0: float = 1.0, d0: float = 0.0, state=None, mode: str = "auto", out=None):
-    """IIR recursion with feedback ADDED (coefficients.h:106-130).  state: [channels, 2*poles] fp32, updated in place."""
+    """IIR recursion with feedback ADDED (coefficients.h:106-130).
+
+    state: [channels, 2*poles] float64 {x[t-1..t-poles], v[t-1..t-poles]}, updated in place
+    (the reference's x[]/y[] history, coefficients.h:11-12)."""
     x, px, mem = _prep(x, np.float32, "float32")
     a = np.ascontiguousarray(a, dtype=np.float64)
     b = np.ascontiguousarray(b, dtype=np.float64)
@@ -132,10 +135,10 @@ def iir(x, a, b, c0: float = 1.0, d0: float = 0.0, state=None, mode: str = "auto
         if _is_torch(state) != _is_torch(x):
             raise capi.DspGpuError(capi.EINVAL, "state must live where x lives")
         if _is_torch(state):
-            if not (state.is_contiguous() and state.dtype == torch.float32 and state.numel() == channels * 2 * poles):
-                raise capi.DspGpuError(capi.EINVAL, "state must be contiguous fp32 [channels, 2*poles]")
-        elif not (state.flags.c_contiguous and state.dtype == np.float32 and state.size == channels * 2 * poles):
-            raise capi.DspGpuError(capi.EINVAL, "state must be contiguous fp32 [channels, 2*poles]")
+            if not (state.is_contiguous() and state.dtype == torch.float64 and state.numel() == channels * 2 * poles):
+                raise capi.DspGpuError(capi.EINVAL, "state must be contiguous float64 [channels, 2*poles]")
+        elif not (state.flags.c_contiguous and state.dtype == np.float64 and state.size == channels * 2 * poles):
+            raise capi.DspGpuError(capi.EINVAL, "state must be contiguous float64 [channels, 2*poles]")
         pstate = _ptr(state)
     capi.check(capi.lib().dsp_gpu_iir(px, _ptr(y), channels, n, a.ctypes.data, b.ctypes.data, poles, float(c0),
                                       float(d0), pstate, _IIR_MODES[mode], mem, _stream_of(x)))

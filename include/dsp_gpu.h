@@ -92,8 +92,11 @@ int dsp_gpu_convolve(const float *x, float *y, size_t channels, size_t n, const 
 
 /*
  * Centred moving average.  Replaces dsp::filter::MovingAverageFilter::apply
- * (filter.h:81-101): y[i] = mean(x[i-mid .. i-mid+npoints-1]) for mid <= i < n-mid with
- * mid = npoints/2, zero elsewhere.  Windows are summed directly (no running sum), so the
+ * (filter.h:81-101): with mid = npoints/2,
+ *     y[i] = (sum_{k=i-mid}^{i+mid} x[k] - (npoints even ? x[npoints] : 0)) / npoints
+ * for mid <= i < n-mid, zero elsewhere -- for odd npoints the plain centred mean; for even
+ * npoints (reachable through numPoints(), filter.h:72-74) exactly what the reference's running
+ * sum evaluates to.  Windows are summed directly (no running sum along the signal), so the
  * result does not carry the reference's accumulated rounding drift.  n >= npoints >= 1.
  */
 int dsp_gpu_moving_average(const float *x, float *y, size_t channels, size_t n, int npoints,
@@ -106,13 +109,15 @@ int dsp_gpu_moving_average(const float *x, float *y, size_t channels, size_t n, 
  *     y[t] = v[t]*c0 + x[t]*d0
  * a, b: HOST pointers to poles+1 doubles (b[0] ignored), as produced by the designers in
  * recursive_filters.h.  1 <= poles <= 8.  Channel-major x[ch][n], y[ch][n].
- * `state` (may be NULL = start from rest, nothing written back) is [ch][2*poles] floats,
+ * Arithmetic and history are double, as in the reference (coefficients.h:9-12); samples are fp32.
+ * `state` (may be NULL = start from rest, nothing written back) is [ch][2*poles] DOUBLES,
  * {x[t-1..t-poles], v[t-1..t-poles]} per channel, read before and written after the call:
  * it is the reference's x[]/y[] history (coefficients.h:11-12) made explicit so a long
- * channel can be fed in chunks.  Lives where `mem` says.
+ * channel can be fed in chunks (chunked == unchunked, bit for bit, in BATCH mode).  Lives
+ * where `mem` says.
  */
 int dsp_gpu_iir(const float *x, float *y, size_t channels, size_t n, const double *a,
-                const double *b, int poles, double c0, double d0, float *state, int mode, int mem,
+                const double *b, int poles, double c0, double d0, double *state, int mode, int mem,
                 void *stream);
 
 /* housekeeping */

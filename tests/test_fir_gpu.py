@@ -1,0 +1,181 @@
+"""GPU parity of FIR convolution (dsp_gpu_convolve) and the moving average through the C ABI.
+
+Tolerances (BASELINE.json north_star), relative L2 against the reference run on the same
+float-exact inputs in double: direct <= 1e-6; overlap-save is FFT-class, <= 1e-5*log2(4096).
+"""
+import numpy as np
+import pytest
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+DIRECT_TOL = 1e-6
+OS_TOL = 1e-5 * 12
+
+
+@pytest.fixture(scope="module")
+def ops(dev):
+    from dsp_amd import ops as _ops
+    return _ops
+
+
+def test_kat_alignment(ops, dev, golden):
+    """SincFilter{0.14,10}.apply(delta[n-15]): zeros for j<10, kernel at j=15..25."""
+    import torch
+    x = golden["fir_kat_in"]
+    h = golden["sinc_0p14_10"]
+    for mode in ("direct", "overlap_save"):
+        got = ops.convolve(torch.from_numpy(x).to(dev), h, mode).cpu().numpy()
+        assert not got[:10].any()
+        assert np.allclose(got, golden["fir_kat_out"], atol=2e-6 if mode == "overlap_save" else 1e-7)
+
+
+@pytest.mark.parametrize("mode,tol", [("direct", DIRECT_TOL), ("overlap_save", OS_TOL), ("auto", OS_TOL)])
+def test_golden_noise_511(ops, dev, golden, mode, tol):
+    import torch
+    x = golden["fir_noise_in"]
+    got = ops.convolve(torch.from_numpy(x).to(dev), golden["sinc_0p1_511"], mode).cpu().numpy()
+    assert not got[:510].any()  # filter.h:133: first M outputs stay zero
+    assert rel_l2(got, golden["fir_noise_511_f64"]) <= tol
+    # the reference's own float instantiation rounds at every tap; we must be at least as close to exact
+    assert rel_l2(got, golden["fir_noise_511_f32"].astype(np.float64)) <= tol + 5e-7
+    assert np.array_equal(got, ops.convolve(x, golden["sinc_0p1_511"], mode))  # host-pointer path
+
+
+def test_golden_highpass_and_tones(ops, dev, golden):
+    import torch
+    x = golden["fir_noise_in"]
+    got = ops.convolve(torch.from_numpy(x).to(dev), golden["sinc_0p2_64_hamming_inv"], "direct").cpu().numpy()
+    want = golden["fir_noise_hp64_f32"].astype(np.float64)
+    assert rel_l2(got, want) <= 2e-6  # vs the float reference (its own rounding included)
+    tone = golden["fir_tone_in"].astype(np.float32)
+    for mode, tol in (("direct", 2e-6), ("overlap_save", OS_TOL)):
+        got = ops.convolve(torch.from_numpy(tone).to(dev), golden["sinc_0p14_200"], mode).cpu().numpy()
+        assert rel_l2(got, golden["fir_tone_out_f64"]) <= tol
+
+
+@pytest.mark.parametrize("channels,n,ntaps", [(1, 64, 1), (3, 100, 11), (2, 2000, 201), (5, 8192, 511), (2, 8193, 511),
+                                              (1, 20, 21), (1, 10, 21), (3, 30001, 64), (2, 16384 + 7, 4096),
+                                              (7, 4099, 33), (1, 70000, 1023), (4, 12288, 2049)])
+def test_direct_vs_oracle(ops, dev, orc, channels, n, ntaps):
+    import torch
+    rng = np.random.default_rng(n * 7 + ntaps)
+    h = rng.standard_normal(ntaps) / np.sqrt(ntaps) if ntaps in (1, 64, 33) else orc.sinc(0.2, ntaps)[:ntaps]
+    x = rng.standard_normal((channels, n)).astype(np.float32)
+    got = ops.convolve(torch.from_numpy(x).to(dev), h, "direct").cpu().numpy()
+    want = orc.fir(x.astype(np.float64), h.astype(np.float32).astype(np.float64))  # the device holds fp32 taps
+    assert got.shape == want.shape
+    if n >= ntaps:
+        assert rel_l2(got, want) <= DIRECT_TOL
+    assert not got[:, : min(n, ntaps - 1)].any()
+    # taps rounded to fp32 stay within the budget of the double-tap reference too
+    if n >= ntaps and ntaps > 1:
+        assert rel_l2(got, orc.fir(x.astype(np.float64), h)) <= DIRECT_TOL
+
+
+@pytest.mark.parametrize("channels,n,ntaps", [(1, 4096, 511), (3, 100, 11), (2, 20000, 511), (2, 3586 * 2 + 510, 511),
+                                              (2, 3586 * 2 + 511, 511), (1, 20, 21), (3, 30001, 64), (2, 50000, 2049),
+                                              (5, 9000, 2), (1, 70000, 1023)])
+def test_overlap_save_vs_oracle(ops, dev, orc, channels, n, ntaps):
+    import torch
+    rng = np.random.default_rng(n * 3 + ntaps)
+    h = orc.sinc(0.15, ntaps)[:ntaps]
+    x = rng.standard_normal((channels, n)).astype(np.float32)
+    got = ops.convolve(torch.from_numpy(x).to(dev), h, "overlap_save").cpu().numpy()
+    want = orc.fir(x.astype(np.float64), h)
+    if n >= ntaps:
+        assert rel_l2(got, want) <= OS_TOL
+    assert not got[:, : min(n, ntaps - 1)].any()
+
+
+def test_output_guard(ops, dev, orc):
+    """Nothing is written outside [ch][n] for ragged sizes."""
+    import torch
+    rng = np.random.default_rng(3)
+    h = orc.sinc(0.1, 101)
+    for mode in ("direct", "overlap_save"):
+        x = rng.standard_normal((3, 5001)).astype(np.float32)
+        guard = torch.full((5, 5001), 9.0, device=dev)
+        ops.convolve(torch.from_numpy(x).to(dev), h, mode, out=guard[1:4])
+        g = guard.cpu().numpy()
+        assert (g[0] == 9).all() and (g[4] == 9).all()
+        assert rel_l2(g[1:4], orc.fir(x.astype(np.float64), h)) <= OS_TOL
+
+
+def test_c3_full_size_properties(ops, dev):
+    """BASELINE config 3 at full size (1,024 ch x 2^20, 511 taps): direct vs overlap-save agree, linearity,
+    impulse response reproduces the taps, DC gain 1."""
+    import torch
+    from dsp_amd import design
+    h = design.sinc(0.1, 511)
+    g = torch.Generator(device=dev).manual_seed(4321)
+    C, N = 1024, 1 << 20
+    x = torch.randn(C, N, device=dev, generator=g)
+    yd = ops.convolve(x, h, "direct")
+    yo = ops.convolve(x, h, "overlap_save")
+    den = torch.linalg.vector_norm(yd.double())
+    assert float(torch.linalg.vector_norm((yd - yo).double()) / den) <= OS_TOL
+    assert float(yd[:, :510].abs().max()) == 0.0 and float(yo[:, :510].abs().max()) == 0.0
+    # linearity on a slice
+    a, b = x[:8], x[8:16]
+    lhs = ops.convolve(1.5 * a - 0.25 * b, h, "direct")
+    rhs = 1.5 * yd[:8] - 0.25 * yd[8:16]
+    assert float(torch.linalg.vector_norm((lhs - rhs).double()) / torch.linalg.vector_norm(rhs.double())) <= 5e-7
+    # impulse -> taps (causal alignment), constant -> DC gain 1 after the transient
+    imp = torch.zeros(2, N, device=dev)
+    imp[0, 1000] = 1.0
+    imp[1, :] = 1.0
+    for mode, tol in (("direct", 1e-7), ("overlap_save", 5e-6)):
+        r = ops.convolve(imp, h, mode).cpu().numpy()
+        assert np.abs(r[0, 1000:1511] - h.astype(np.float32)).max() <= tol
+        assert np.abs(r[0, 1511:]).max() <= tol and np.abs(r[0, :1000]).max() <= tol
+        assert np.abs(r[1, 510:] - 1.0).max() <= 20 * tol + 2e-6
+
+
+# ---- moving average ---------------------------------------------------------------------------
+def test_mavg_kat(ops, dev, golden):
+    import torch
+    got = ops.moving_average(torch.arange(16, dtype=torch.float32, device=dev), 5).cpu().numpy()
+    assert np.array_equal(got, golden["mavg_kat_out"])
+
+
+@pytest.mark.parametrize("channels,n,pts", [(1, 8192, 511), (1, 8192, 8), (3, 1000, 511), (2, 511, 511), (2, 64, 1),
+                                            (2, 30000, 4096), (2, 30000, 4097), (3, 9001, 100), (1, 8, 8), (1, 9, 8),
+                                            (2, 5000, 2), (2, 5000, 3)])
+def test_mavg_vs_oracle(ops, dev, orc, channels, n, pts):
+    import torch
+    rng = np.random.default_rng(n + pts)
+    x = rng.standard_normal((channels, n)).astype(np.float32)
+    got = ops.moving_average(torch.from_numpy(x).to(dev), pts).cpu().numpy()
+    want = orc.moving_average(x.astype(np.float64), pts)  # even lengths included: numPoints() does not re-force odd
+    assert rel_l2(got, want) <= 1e-6, (n, pts)
+    mid = pts // 2
+    assert not got[:, :mid].any()
+    if n - mid > mid + 1:
+        assert not got[:, n - mid:].any()
+
+
+def test_mavg_golden(ops, dev, golden):
+    import torch
+    x = golden["fir_noise_in"]
+    xd = torch.from_numpy(x).to(dev)
+    assert rel_l2(ops.moving_average(xd, 511).cpu().numpy(), golden["mavg_noise_511_f64"]) <= 1e-6
+    # the reference's float running sum drifts; its double instantiation is the yardstick,
+    # the float one only has to be within its own drift
+    assert rel_l2(ops.moving_average(xd, 511).cpu().numpy(), golden["mavg_noise_511_f32"].astype(np.float64)) <= 1e-4
+    got8 = ops.moving_average(xd, 8).cpu().numpy()
+    assert rel_l2(got8, golden["mavg_noise_even8_f32"].astype(np.float64)) <= 1e-5
+    assert np.array_equal(got8, ops.moving_average(x, 8))
+
+
+def test_errors(ops, dev):
+    import torch
+    from dsp_amd import capi
+    x = torch.zeros(2, 100, device=dev)
+    with pytest.raises(capi.DspGpuError):
+        ops.convolve(x, np.zeros(3000), "overlap_save")
+    with pytest.raises(capi.DspGpuError):
+        ops.convolve(x, np.zeros(5000), "direct")
+    with pytest.raises(capi.DspGpuError):
+        ops.moving_average(x, 101)
