@@ -65,7 +65,7 @@ def test_impulse_kat(ops, dev, golden):
         v[t + 4] = (a[t] if t < 5 else 0.0) + sum(b[i] * v[t + 4 - i] for i in range(1, 5))
     assert np.allclose(got, v[4:], rtol=2e-7, atol=1e-9)
     # the fixture is the reference's float instantiation, which rounds every fed-back output to float
-    assert np.allclose(got, golden["cheby_lp4_impulse32"], rtol=1e-5, atol=1e-8)
+    assert np.allclose(got, golden["cheby_lp4_impulse32"], rtol=1e-5, atol=5e-7)
 
 
 @pytest.mark.parametrize("mode", ["batch", "scan"])
