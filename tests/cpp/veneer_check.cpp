@@ -1,0 +1,146 @@
+// veneer_check.cpp -- exercises include/dsp_mi355x/dsp.hpp the way the reference's eval programs call
+// the reference (test infrastructure; driven by tests/test_cpp_veneer.py).
+//
+//   veneer_check design            prints the host-side designs (no GPU needed)
+//   veneer_check run <dir>         reads <dir>/*.f32 written by the test, runs every veneer call on the
+//                                  GPU and writes the results next to them
+#define DSP_MI355X_AS_DSP
+#include <dsp_mi355x/dsp.hpp>
+
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+
+namespace {
+template <typename T>
+std::vector<T> slurp(const std::string &path) {
+    std::ifstream f(path, std::ios::binary | std::ios::ate);
+    if (!f) throw std::runtime_error("cannot read " + path);
+    const std::streamsize bytes = f.tellg();
+    f.seekg(0);
+    std::vector<T> v(static_cast<size_t>(bytes) / sizeof(T));
+    f.read(reinterpret_cast<char *>(v.data()), bytes);
+    return v;
+}
+template <typename T>
+void dump(const std::string &path, const T *p, size_t n) {
+    std::ofstream f(path, std::ios::binary);
+    f.write(reinterpret_cast<const char *>(p), static_cast<std::streamsize>(n * sizeof(T)));
+}
+template <typename C>
+void line(const char *name, const C &v) {
+    std::printf("%s", name);
+    for (double d : v) std::printf(" %.17g", d);
+    std::printf("\n");
+}
+template <size_t P>
+void coef(const char *name, const dsp::Coefficients<P> &c) {
+    line((std::string(name) + "_a").c_str(), c.a);
+    line((std::string(name) + "_b").c_str(), c.b);
+    const double cd[2] = {c.c0, c.d0};
+    line((std::string(name) + "_cd").c_str(), std::vector<double>(cd, cd + 2));
+}
+
+int design() {
+    using namespace dsp;
+    line("sinc_0p14_10", sinc(0.14, 10));
+    line("sinc_0p1_511", sinc(0.1, 511));
+    line("sinc_0p14_200", sinc(0.14, 200));
+    line("sinc_0p2_64_hamming_inv", sinc<InversionType::SpectralInversion>(0.2, 64, Windows::hamming));
+    line("sinc_0p2_64_blackman_rev", sinc<InversionType::SpectralReversal>(0.2, 64));
+    line("sinc_0p3_31_identity", sinc(0.3, 31, Windows::identity));
+    line("filter_kernel_0p14_200", filter::SincFilter<>(0.14, 200).kernel());
+    coef("cheby_lp2", recursive::lowPassFilter<2>(0.1));
+    coef("cheby_lp4", recursive::lowPassFilter<4>(0.1));
+    coef("cheby_lp6", recursive::lowPassFilter<6>(0.1));
+    coef("cheby_hp4", recursive::highPassFilter<4>(0.1));
+    coef("cheby_lp4_lo", recursive::lowPassFilter<>(0.01));
+    coef("cheby_lp8", recursive::lowPassFilter<8>(0.2));
+    coef("bq_bp", recursive::bandPassFilter(0.1, 0.01));
+    coef("bq_br", recursive::bandRejectFilter(0.2, 0.02));
+    coef("bq_ls", recursive::lowShelf(0.3, 6.0));
+    coef("bq_hs", recursive::highShelf(0.5, -3.0));
+    coef("bq_pk", recursive::peakingFilter(0.4, 4.0, 0.7));
+    return 0;
+}
+
+int run(const std::string &dir) {
+    using namespace dsp;
+    // fft0: 3 transforms of 1024 complex points, forward then inverse of the result
+    {
+        auto in = slurp<std::complex<float>>(dir + "/fft_in.c64");
+        std::vector<std::complex<float>> fwd(in.size()), back(in.size());
+        fft0<FFTType::FORWARD>(in.data(), fwd.data(), 10, in.size() / 1024);
+        fft0<FFTType::INVERSE>(fwd.data(), back.data(), 10, in.size() / 1024);
+        dump(dir + "/fft_fwd.c64", fwd.data(), fwd.size());
+        dump(dir + "/fft_back.c64", back.data(), back.size());
+    }
+    // eval/recursive_filters/main.cpp:104-121: impulse at N/2 -> filter -> 1024-point fft
+    {
+        SampleBuffer<float> impulse(1024, 0.0f);
+        impulse[512] = 1.0f;
+        auto filt = recursive::lowPassFilter<4>(0.1);
+        auto response = filt(impulse, DSP_GPU_IIR_BATCH);
+        std::vector<std::complex<double>> freq(1024);
+        fft(response.begin(), response.end(), freq.begin(), 1024);
+        dump(dir + "/chain_response.f32", response.data(), response.size());
+        dump(dir + "/chain_fft.c128", freq.data(), freq.size());
+    }
+    // SincFilter (filter.h:123-140) on 2 channels, direct, and convolve<Domain::Frequency>
+    {
+        auto x = slurp<float>(dir + "/fir_in.f32");
+        SampleBuffer<float> sig(x.begin(), x.end());
+        filter::SincFilter<> f(0.1, 511);
+        auto y = f.apply(sig, 2);
+        dump(dir + "/fir_direct.f32", y.data(), y.size());
+        SampleBuffer<float> one(x.begin(), x.begin() + x.size() / 2);
+        const auto k = f.kernel();
+        SampleBuffer<double> kern(k.begin(), k.end());
+        auto yt = convolve<Domain::Time>(one, kern);
+        auto yf = convolve<Domain::Frequency>(one, kern);
+        dump(dir + "/conv_time.f32", yt.data(), yt.size());
+        dump(dir + "/conv_freq.f32", yf.data(), yf.size());
+        filter::MovingAverageFilter ma(511);
+        auto ym = ma(one);
+        dump(dir + "/mavg.f32", ym.data(), ym.size());
+        ma.numPoints(8);
+        auto y8 = ma.apply(one);
+        dump(dir + "/mavg8.f32", y8.data(), y8.size());
+    }
+    // Coefficients<4>: two chunks with the object's own history carried, then a shelving biquad
+    {
+        auto x = slurp<float>(dir + "/iir_in.f32");
+        auto filt = recursive::lowPassFilter<4>(0.1);
+        SampleBuffer<float> a(x.begin(), x.begin() + 1500), b(x.begin() + 1500, x.end());
+        auto ya = filt(a), yb = filt(b);
+        std::vector<float> y(ya.begin(), ya.end());
+        y.insert(y.end(), yb.begin(), yb.end());
+        dump(dir + "/iir_lp4.f32", y.data(), y.size());
+        std::vector<double> hist(filt.x.begin(), filt.x.end());
+        hist.insert(hist.end(), filt.y.begin(), filt.y.end());
+        dump(dir + "/iir_lp4_state.f64", hist.data(), hist.size());
+        auto shelf = recursive::lowShelf(0.3, 6.0);
+        SampleBuffer<float> all(x.begin(), x.end());
+        auto ys = shelf(all);
+        dump(dir + "/iir_ls.f32", ys.data(), ys.size());
+        // batched rows through the same coefficients
+        std::vector<float> rows(x.size());
+        recursive::lowPassFilter<4>(0.1).apply(x.data(), rows.data(), 4, x.size() / 4);
+        dump(dir + "/iir_rows.f32", rows.data(), rows.size());
+    }
+    std::printf("veneer run ok (%s, %d device(s))\n", dsp_gpu_version(), dsp_gpu_device_count());
+    return 0;
+}
+}  // namespace
+
+int main(int argc, char **argv) {
+    try {
+        if (argc >= 2 && !std::strcmp(argv[1], "design")) return design();
+        if (argc >= 3 && !std::strcmp(argv[1], "run")) return run(argv[2]);
+    } catch (const std::exception &e) {
+        std::fprintf(stderr, "veneer_check: %s\n", e.what());
+        return 2;
+    }
+    std::fprintf(stderr, "usage: veneer_check design | run <dir>\n");
+    return 1;
+}

@@ -1,0 +1,84 @@
+"""The C++ drop-in layer (include/dsp_mi355x/dsp.hpp) driven through tests/cpp/veneer_check.
+
+CPU: the host-side designs it computes are the reference's, bit for bit (golden fixture), and the
+header compiles against the reference's own SampleBuffer where /root/reference exists.
+GPU: every veneer call, used the way the reference's eval programs use the reference, against the oracle.
+"""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import rel_l2
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "tests", "cpp", "veneer_check")
+
+
+def _exe():
+    if not os.path.exists(EXE):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "cpp")], check=True, capture_output=True)
+    return EXE
+
+
+def test_designs_match_golden(golden):
+    out = subprocess.run([_exe(), "design"], check=True, capture_output=True, text=True).stdout
+    got = {ln.split()[0]: np.array([float(v) for v in ln.split()[1:]]) for ln in out.splitlines()}
+    for key in ("sinc_0p14_10", "sinc_0p1_511", "sinc_0p14_200", "sinc_0p2_64_hamming_inv", "sinc_0p2_64_blackman_rev",
+                "sinc_0p3_31_identity"):
+        assert got[key].tobytes() == golden[key].tobytes(), key
+    assert got["filter_kernel_0p14_200"].tobytes() == golden["sinc_0p14_200"].tobytes()
+    for tag in ("lp2", "lp4", "lp6", "hp4", "lp4_lo", "lp8"):
+        assert got[f"cheby_{tag}_a"].tobytes() == golden[f"cheby_{tag}_a"].tobytes(), tag
+        assert got[f"cheby_{tag}_b"].tobytes() == golden[f"cheby_{tag}_b"].tobytes(), tag
+    for tag in ("bp", "br", "ls", "hs", "pk"):
+        for part in ("a", "b", "cd"):
+            assert got[f"bq_{tag}_{part}"].tobytes() == golden[f"bq_{tag}_{part}"].tobytes(), (tag, part)
+
+
+def test_compiles_against_the_reference_container():
+    if not os.path.isdir("/root/reference/dsp/include/dsp"):
+        pytest.skip("no /root/reference here")
+    subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "cpp"), "syntax_with_reference"], check=True,
+                   capture_output=True)
+
+
+@pytest.mark.gpu
+def test_veneer_on_gpu(tmp_path, orc, golden, dev):
+    rng = np.random.default_rng(77)
+    d = str(tmp_path)
+    fft_in = (rng.standard_normal((3, 1024)) + 1j * rng.standard_normal((3, 1024))).astype(np.complex64)
+    fft_in.tofile(os.path.join(d, "fft_in.c64"))
+    fir_in = rng.standard_normal((2, 6000)).astype(np.float32)
+    fir_in.tofile(os.path.join(d, "fir_in.f32"))
+    iir_in = golden["iir_noise_in"]
+    iir_in.tofile(os.path.join(d, "iir_in.f32"))
+    p = subprocess.run([_exe(), "run", d], capture_output=True, text=True, timeout=110)
+    assert p.returncode == 0, p.stderr
+    rd = lambda name, dt: np.fromfile(os.path.join(d, name), dtype=dt)
+
+    fwd = orc.fft0(fft_in.astype(np.complex128))
+    assert rel_l2(rd("fft_fwd.c64", np.complex64).reshape(3, 1024), fwd) <= 1e-4
+    assert rel_l2(rd("fft_back.c64", np.complex64).reshape(3, 1024), 1024 * fft_in.astype(np.complex128)) <= 2e-4
+
+    assert rel_l2(rd("chain_response.f32", np.float32), orc.iir(np.eye(1, 1024, 512)[0], golden["cheby_lp4_a"], golden["cheby_lp4_b"])) <= 2e-6
+    resp = rd("chain_response.f32", np.float32).astype(np.float64)
+    assert rel_l2(rd("chain_fft.c128", np.complex128), orc.fft_real(resp, 1024)) <= 1e-4
+
+    h = golden["sinc_0p1_511"]
+    want = orc.fir(fir_in.astype(np.float64), h)
+    assert rel_l2(rd("fir_direct.f32", np.float32).reshape(2, 6000), want) <= 1e-6
+    assert rel_l2(rd("conv_time.f32", np.float32), want[0]) <= 1e-6
+    assert rel_l2(rd("conv_freq.f32", np.float32), want[0]) <= 1.2e-4
+    assert rel_l2(rd("mavg.f32", np.float32), orc.moving_average(fir_in[0].astype(np.float64), 511)) <= 1e-6
+    assert rel_l2(rd("mavg8.f32", np.float32), orc.moving_average(fir_in[0].astype(np.float64), 8)) <= 1e-6
+
+    assert rel_l2(rd("iir_lp4.f32", np.float32), golden["cheby_lp4_y64"]) <= 2e-6
+    st = rd("iir_lp4_state.f64", np.float64)
+    ref = golden["cheby_lp4_state_end"]
+    assert np.array_equal(st[1:5], ref[1:5]) and st[0] == 0
+    assert np.allclose(st[6:10], ref[6:10], rtol=1e-5, atol=1e-7)
+    assert rel_l2(rd("iir_ls.f32", np.float32), golden["bq_ls_y64"]) <= 2e-6
+    rows = iir_in.reshape(4, -1).astype(np.float64)
+    assert rel_l2(rd("iir_rows.f32", np.float32).reshape(4, -1), orc.iir(rows, golden["cheby_lp4_a"], golden["cheby_lp4_b"])) <= 2e-6
