@@ -38,6 +38,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="fft",
                     choices=["fft", "fir_direct", "fir_os", "iir_batch", "iir_scan", "mavg"])
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: every GPU gets the full per-GPU batch; strong: the one-GPU batch is channel-sharded")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the CPU baseline sample")
     return ap.parse_args()
@@ -46,8 +48,17 @@ def parse():
 # ----------------------------------------------------------------------------------------------
 # workloads: each returns (step_fn, units_per_step, meta)
 # ----------------------------------------------------------------------------------------------
+SHARD = (0, 1)  # (rank, world) when --scaling strong channel-shards the one-GPU batch
+
+
+def _share(total):
+    from dsp_amd import multigpu
+    lo, hi = multigpu.shard_range(total, *SHARD)
+    return hi - lo
+
+
 def make_fft(torch, dev, ops, rank):
-    batch, n = 65536, 4096
+    batch, n = _share(65536), 4096
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     x = torch.view_as_complex(torch.randn(batch, n, 2, device=dev, generator=g))
     out = torch.empty_like(x)
@@ -64,7 +75,7 @@ def make_fft(torch, dev, ops, rank):
 
 
 def make_fir(torch, dev, ops, rank, mode):
-    channels, n, ntaps = 1024, 1 << 20, 511
+    channels, n, ntaps = _share(1024), 1 << 20, 511
     taps = sinc_taps_host(0.1, ntaps)
     g = torch.Generator(device=dev).manual_seed(4321 + rank)
     x = torch.randn(channels, n, device=dev, generator=g)
@@ -87,7 +98,7 @@ def make_fir(torch, dev, ops, rank, mode):
 
 
 def make_mavg(torch, dev, ops, rank):
-    channels, n, pts = 1024, 1 << 20, 511
+    channels, n, pts = _share(1024), 1 << 20, 511
     g = torch.Generator(device=dev).manual_seed(99 + rank)
     x = torch.randn(channels, n, device=dev, generator=g)
     y = torch.empty_like(x)
@@ -105,7 +116,7 @@ def make_mavg(torch, dev, ops, rank):
 def make_iir(torch, dev, ops, rank, mode):
     a, b = cheby_lp4_host()
     if mode == "batch":
-        channels, n = 262144, 4096
+        channels, n = _share(262144), 4096
         wl = "C4a: 4-pole Chebyshev low-pass, 262,144 ch x 4,096 samples fp32 noise (batch-parallel), per GPU"
     else:
         channels, n = 1, 1 << 28
@@ -198,8 +209,11 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
-    from dsp_amd import ops
+    from dsp_amd import multigpu, ops
 
+    global SHARD
+    if args.scaling == "strong":
+        SHARD = (rank, world)
     if args.workload == "fft":
         step, units, meta = make_fft(torch, dev, ops, rank)
     elif args.workload in ("fir_direct", "fir_os"):
@@ -233,13 +247,11 @@ def main():
     elapsed = time.perf_counter() - t0
     kernel_ms = e0.elapsed_time(e1) / args.steps
 
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = multigpu.max_over_ranks(elapsed, dev)
+    all_units = multigpu.sum_over_ranks(float(units), dev)  # ranks may own unequal shares under strong scaling
 
     if rank == 0:
-        total_units = units * world * args.steps
+        total_units = all_units * args.steps
         value = total_units / elapsed / 1e9
         launch_s = kernel_ms * 1e-3
         if meta["bound"] == "hbm":
@@ -254,7 +266,7 @@ def main():
                      "launch_ms": kernel_ms, "algorithmic": meta["alg_unit"]})
         line = {"metric": meta["metric"], "value": value, "unit": meta["unit"], "n_gpus": world, "steps": args.steps,
                 "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-                "scaling": "weak", "vs_baseline": None, "dtype": meta["dtype"], "data": "synthetic",
+                "scaling": args.scaling, "vs_baseline": None, "dtype": meta["dtype"], "data": "synthetic",
                 "config": meta["config"], "roofline": roof}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_seconds)

@@ -30,6 +30,9 @@ EXPORTS = (
     "dsp_gpu_shutdown",
     "dsp_gpu_version",
     "dsp_gpu_fft_batch_timed",
+    "dsp_gpu_fft_columns",
+    "dsp_gpu_swap_axes",
+    "dsp_gpu_transpose_blocks",
 )
 
 
@@ -56,6 +59,11 @@ def lib() -> C.CDLL:
         L.dsp_gpu_convolve.argtypes = [vp, vp, sz, sz, vp, i, i, i, vp]
         L.dsp_gpu_moving_average.argtypes = [vp, vp, sz, sz, i, i, vp]
         L.dsp_gpu_iir.argtypes = [vp, vp, sz, sz, vp, vp, i, C.c_double, C.c_double, vp, i, i, vp]
+        L.dsp_gpu_fft_columns.argtypes = [vp, vp, i, sz, i, vp]
+        L.dsp_gpu_swap_axes.argtypes = [vp, vp, sz, sz, sz, i, sz, i, vp]
+        L.dsp_gpu_transpose_blocks.argtypes = [vp, vp, sz, sz, sz, vp]
+        for name in ("dsp_gpu_fft_columns", "dsp_gpu_swap_axes", "dsp_gpu_transpose_blocks"):
+            getattr(L, name).restype = i
         for name in ("dsp_gpu_fft_batch", "dsp_gpu_fft_batch_timed", "dsp_gpu_fft_real_batch", "dsp_gpu_convolve",
                      "dsp_gpu_moving_average", "dsp_gpu_iir", "dsp_gpu_device_count", "dsp_gpu_shutdown"):
             getattr(L, name).restype = i

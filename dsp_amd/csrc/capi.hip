@@ -336,6 +336,31 @@ int dsp_gpu_iir(const float *x, float *y, size_t channels, size_t n, const doubl
     return DSP_GPU_OK;
 }
 
+int dsp_gpu_fft_columns(const void *in, void *out, int log2n, size_t cols, int direction, void *stream) {
+    if (!in || !out) return fail(DSP_GPU_EINVAL, "dsp_gpu_fft_columns: null buffer");
+    if (direction != DSP_GPU_FORWARD && direction != DSP_GPU_INVERSE)
+        return fail(DSP_GPU_EINVAL, "dsp_gpu_fft_columns: direction %d", direction);
+    if (cols == 0) return DSP_GPU_OK;
+    return launch_fft_columns(static_cast<const float2 *>(in), static_cast<float2 *>(out), log2n, cols, direction,
+                              static_cast<hipStream_t>(stream));
+}
+
+int dsp_gpu_swap_axes(const void *in, void *out, size_t a, size_t b, size_t c, int tw_log2n, size_t tw_row0,
+                      int direction, void *stream) {
+    if (!in || !out || in == out) return fail(DSP_GPU_EINVAL, "dsp_gpu_swap_axes: null or aliased buffer");
+    if (tw_log2n < 0 || tw_log2n > 40) return fail(DSP_GPU_EINVAL, "dsp_gpu_swap_axes: tw_log2n %d", tw_log2n);
+    if (direction != DSP_GPU_FORWARD && direction != DSP_GPU_INVERSE)
+        return fail(DSP_GPU_EINVAL, "dsp_gpu_swap_axes: direction %d", direction);
+    return launch_swap_axes(static_cast<const float2 *>(in), static_cast<float2 *>(out), a, b, c, tw_log2n, tw_row0,
+                            direction, static_cast<hipStream_t>(stream));
+}
+
+int dsp_gpu_transpose_blocks(const void *in, void *out, size_t blocks, size_t rows, size_t cols, void *stream) {
+    if (!in || !out || in == out) return fail(DSP_GPU_EINVAL, "dsp_gpu_transpose_blocks: null or aliased buffer");
+    return launch_transpose_blocks(static_cast<const float2 *>(in), static_cast<float2 *>(out), blocks, rows, cols,
+                                   static_cast<hipStream_t>(stream));
+}
+
 int dsp_gpu_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;

@@ -48,6 +48,10 @@ void release_all_workspaces();
 int launch_fft_batch(const float2 *in, float2 *out, int log2n, size_t batch, int direction, hipStream_t s);
 int launch_fft_real_batch(const float *in, size_t n_in, size_t in_stride, float2 *out, int log2n,
                           size_t batch, int direction, int shifted, hipStream_t s);
+int launch_fft_columns(const float2 *in, float2 *out, int log2n, size_t cols, int direction, hipStream_t s);
+int launch_swap_axes(const float2 *in, float2 *out, size_t a, size_t b, size_t c, int tw_log2,
+                     unsigned long long row0, int direction, hipStream_t s);
+int launch_transpose_blocks(const float2 *in, float2 *out, size_t blocks, size_t rows, size_t cols, hipStream_t s);
 int launch_fir_direct(const float *x, float *y, size_t channels, size_t n, const float *d_taps,
                       int ntaps, hipStream_t s);
 int launch_fir_overlap_save(const float *x, float *y, size_t channels, size_t n, const float2 *d_hspec,

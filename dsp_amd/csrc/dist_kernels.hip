@@ -1,0 +1,106 @@
+// dist_kernels.hip -- local steps of the multi-GPU (six-step) FFT for gfx950.
+//
+// One transform of N = N1*N2 points, larger than one GPU wants to hold (BASELINE config 5: 2^30),
+// is dsp::fft0 (reference fft.h:31-55) decomposed as   n = n1*N2 + n2,  k = k1 + N1*k2:
+//     X[k1 + N1 k2] = sum_n2 W_N2^{n2 k2} * W_N^{n2 k1} * ( sum_n1 x[n1 N2 + n2] W_N1^{n1 k1} )
+// Every rank owns a contiguous N/G slice.  The three all-to-all exchanges are done by the host layer
+// (dsp_amd/dist_fft.py, RCCL through torch.distributed); the kernels here are what runs between them:
+//   fft columns      FFT along axis 0 of a row-major [n][cols] matrix (the sum over n1), built from
+//                    the column passes of fft_kernels.hip
+//   swap_axes        out[b][a][c] = in[a][b][c], optionally times W_N^{(row0+b)*(a*C+c)}: the pack /
+//                    unpack around an exchange with the inter-step twiddle fused
+//   transpose_blocks out[col][blk][row] = in[blk][row][col]: the final reordering to natural order
+#include <algorithm>
+
+#include "common.h"
+#include "fft_device.h"
+
+namespace dspgpu {
+namespace {
+
+constexpr int kDistThreads = 256;
+
+template <int SIGN>
+DSP_DEV c32 unit_root_wide(unsigned long long num, int log2den) {
+    // exponents here reach 2^30 and more: evaluate the angle in double (exact dyadic fraction)
+    double sn, cs;
+    sincospi(static_cast<double>(num) * __builtin_ldexp(2.0, -log2den), &sn, &cs);
+    return make_float2(static_cast<float>(cs), static_cast<float>(SIGN > 0 ? sn : -sn));
+}
+
+// two complex values per thread (16-byte accesses); C is even
+template <int SIGN, bool TW>
+__global__ __launch_bounds__(kDistThreads) void swap_axes_kernel(const float4 *__restrict__ in, float4 *__restrict__ out,
+                                                                 size_t A, size_t B, size_t C2, int tw_log2,
+                                                                 unsigned long long row0) {
+    const size_t total = A * B * C2;
+    for (size_t i = static_cast<size_t>(blockIdx.x) * kDistThreads + threadIdx.x; i < total;
+         i += static_cast<size_t>(gridDim.x) * kDistThreads) {
+        const size_t c2 = i % C2, ab = i / C2;
+        const size_t a = ab / B, b = ab % B;
+        float4 v = in[i];
+        if (TW) {
+            const unsigned long long mask = (1ull << tw_log2) - 1ull;
+            const unsigned long long col = a * (2 * C2) + 2 * c2;
+            const unsigned long long row = row0 + b;
+            const c32 w0 = unit_root_wide<SIGN>((row * col) & mask, tw_log2);
+            const c32 w1 = unit_root_wide<SIGN>((row * (col + 1)) & mask, tw_log2);
+            const c32 p0 = cmul(make_float2(v.x, v.y), w0), p1 = cmul(make_float2(v.z, v.w), w1);
+            v = make_float4(p0.x, p0.y, p1.x, p1.y);
+        }
+        out[(b * A + a) * C2 + c2] = v;
+    }
+}
+
+// 32x32 tiles through LDS; in[blk][row][col] -> out[col][blk][row]
+__global__ __launch_bounds__(kDistThreads) void transpose_blocks_kernel(const c32 *__restrict__ in, c32 *__restrict__ out,
+                                                                        size_t blocks, size_t rows, size_t cols) {
+    __shared__ c32 tile[32][33];
+    const size_t tiles_c = (cols + 31) / 32, tiles_r = (rows + 31) / 32;
+    const size_t t = blockIdx.x;
+    const size_t blk = t / (tiles_r * tiles_c), rem = t % (tiles_r * tiles_c);
+    const size_t r0 = (rem / tiles_c) * 32, c0 = (rem % tiles_c) * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    const c32 *src = in + blk * rows * cols;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const size_t r = r0 + ty + 8 * k, c = c0 + tx;
+        if (r < rows && c < cols) tile[ty + 8 * k][tx] = src[r * cols + c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const size_t c = c0 + ty + 8 * k, r = r0 + tx;
+        if (r < rows && c < cols) out[(c * blocks + blk) * rows + r] = tile[tx][ty + 8 * k];
+    }
+}
+
+}  // namespace
+
+int launch_swap_axes(const float2 *in, float2 *out, size_t a, size_t b, size_t c, int tw_log2, unsigned long long row0,
+                     int direction, hipStream_t s) {
+    if (c % 2) return fail(DSP_GPU_EINVAL, "swap_axes: inner extent %zu must be even", c);
+    const size_t total = a * b * (c / 2);
+    if (total == 0) return DSP_GPU_OK;
+    const unsigned grid = static_cast<unsigned>(std::min<size_t>((total + kDistThreads - 1) / kDistThreads, 1u << 20));
+    const float4 *i4 = reinterpret_cast<const float4 *>(in);
+    float4 *o4 = reinterpret_cast<float4 *>(out);
+    if (tw_log2 <= 0)
+        hipLaunchKernelGGL((swap_axes_kernel<+1, false>), dim3(grid), dim3(kDistThreads), 0, s, i4, o4, a, b, c / 2, 0, 0ull);
+    else if (direction == DSP_GPU_FORWARD)
+        hipLaunchKernelGGL((swap_axes_kernel<+1, true>), dim3(grid), dim3(kDistThreads), 0, s, i4, o4, a, b, c / 2, tw_log2, row0);
+    else
+        hipLaunchKernelGGL((swap_axes_kernel<-1, true>), dim3(grid), dim3(kDistThreads), 0, s, i4, o4, a, b, c / 2, tw_log2, row0);
+    return check_launch("swap_axes_kernel");
+}
+
+int launch_transpose_blocks(const float2 *in, float2 *out, size_t blocks, size_t rows, size_t cols, hipStream_t s) {
+    const size_t tiles = blocks * ((rows + 31) / 32) * ((cols + 31) / 32);
+    if (tiles == 0) return DSP_GPU_OK;
+    if (tiles > 0x7fffffffull) return fail(DSP_GPU_EUNSUPPORTED, "transpose_blocks: grid too large");
+    hipLaunchKernelGGL(transpose_blocks_kernel, dim3(static_cast<unsigned>(tiles)), dim3(kDistThreads), 0, s, in, out, blocks,
+                       rows, cols);
+    return check_launch("transpose_blocks_kernel");
+}
+
+}  // namespace dspgpu

@@ -296,6 +296,30 @@ int launch_fft_batch(const float2 *in, float2 *out, int log2n, size_t batch, int
     return launch_large(in, out, log2n, batch, direction, s);
 }
 
+// FFT along axis 0 of a row-major [n][cols] matrix (n = 2^log2n <= 65536), natural order out.
+//   n <= 256: one column pass.  Otherwise n = na*nb:
+//   pass 1  [na][nb*cols]   FFT over na, twiddle W_n^{ka*nb_index}, store -> [nb][ka][cols]
+//   pass 2  [nb][ka*cols]   FFT over nb                              -> [kb][ka][cols] = [k][cols]
+int launch_fft_columns(const float2 *in, float2 *out, int log2n, size_t cols, int direction, hipStream_t s) {
+    if (log2n < 4 || log2n > 16) return fail(DSP_GPU_EINVAL, "fft_columns: log2n %d outside [4,16]", log2n);
+    if (in == out) return fail(DSP_GPU_EINVAL, "fft_columns: in-place is not supported");
+    if (log2n <= 8) {
+        const size_t n = static_cast<size_t>(1) << log2n;
+        const ColumnPlan p{cols, cols, 0, cols, 0};
+        (void)n;
+        return launch_column(log2n, in, out, p, 1, direction, s);
+    }
+    const int la = (log2n + 1) / 2, lb = log2n - la;
+    const size_t na = static_cast<size_t>(1) << la, nb = static_cast<size_t>(1) << lb;
+    void *scratch_v = nullptr;
+    if (int rc = workspace(WS_SCRATCH_B, (na * nb * cols) * sizeof(c32), &scratch_v)) return rc;
+    c32 *scratch = static_cast<c32 *>(scratch_v);
+    const ColumnPlan p1{nb * cols, cols, na * cols, cols, log2n};
+    if (int rc = launch_column(la, in, scratch, p1, 1, direction, s)) return rc;
+    const ColumnPlan p2{na * cols, na * cols, 0, na * cols, 0};
+    return launch_column(lb, scratch, out, p2, 1, direction, s);
+}
+
 int launch_fft_real_batch(const float *in, size_t n_in, size_t in_stride, float2 *out, int log2n, size_t batch,
                           int direction, int shifted, hipStream_t s) {
     if (batch == 0) return DSP_GPU_OK;

@@ -1,0 +1,151 @@
+"""One FFT spread over several GPUs: the six-step decomposition with all-to-all exchanges (config C5).
+
+dsp::fft0 (reference fft.h:31-55) of N = 2^log2n points where every rank holds a contiguous N/G
+slice of the input and receives the same slice of the natural-order output.  With N = N1*N2,
+n = n1*N2 + n2, k = k1 + N1*k2 and W_M = exp(+-2 pi i / M) (+ for the reference's FORWARD):
+
+    X[k1 + N1 k2] = sum_n2 W_N2^{n2 k2} * W_N^{n2 k1} * ( sum_n1 x[n1 N2 + n2] W_N1^{n1 k1} )
+
+    pack -> [all-to-all] -> FFT over n1 -> [all-to-all] -> unpack * twiddle -> FFT over n2
+         -> pack -> [all-to-all] -> transpose to natural order
+
+The exchange is the only collective on the whole hot path; it is point-to-point by nature (every
+pair of GPUs trades one block), which is what the xGMI mesh wants: `all_to_all_single` over RCCL,
+one block of N/G^2 points per peer (128 MiB for 2^30 points on 8 GPUs), no ring.  The local steps
+are the HIP kernels behind dsp_gpu_fft_columns / dsp_gpu_swap_axes / dsp_gpu_fft_batch /
+dsp_gpu_transpose_blocks.  One process per GPU drives this through torch.distributed; `simulate`
+runs the same phases for G virtual ranks inside one process (how the index logic is tested on a
+single GPU, and on CPU with a stand-in for the local steps).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+
+@dataclass(frozen=True)
+class Plan:
+    log2n: int
+    world: int
+    n1: int
+    n2: int
+
+    @property
+    def rows(self) -> int:  # R: rows of the [N1][N2] view per rank
+        return self.n1 // self.world
+
+    @property
+    def cols(self) -> int:  # C: columns per rank after the first exchange
+        return self.n2 // self.world
+
+
+def make_plan(log2n: int, world: int) -> Plan:
+    if world < 1 or world & (world - 1):
+        raise ValueError("world size must be a power of two")
+    l1 = (log2n + 1) // 2
+    n1, n2 = 1 << l1, 1 << (log2n - l1)
+    if n1 % world or n2 % world or n2 // world < 2:
+        raise ValueError(f"2^{log2n} points cannot be spread over {world} ranks")
+    return Plan(log2n, world, n1, n2)
+
+
+class GpuLocalOps:
+    """Local steps on torch CUDA complex64 tensors through the C ABI (current torch stream)."""
+
+    def __init__(self):
+        import torch
+
+        from . import capi
+        self.torch, self.capi = torch, capi
+
+    def _stream(self, t):
+        return self.torch.cuda.current_stream(t.device).cuda_stream
+
+    def swap_axes(self, t, a, b, c, tw_log2n=0, row0=0, inverse=False):
+        out = self.torch.empty_like(t)
+        self.capi.check(self.capi.lib().dsp_gpu_swap_axes(t.data_ptr(), out.data_ptr(), a, b, c, tw_log2n, row0,
+                                                          int(inverse), self._stream(t)))
+        return out
+
+    def fft_columns(self, t, n, cols, inverse=False):
+        out = self.torch.empty_like(t)
+        self.capi.check(self.capi.lib().dsp_gpu_fft_columns(t.data_ptr(), out.data_ptr(), n.bit_length() - 1, cols,
+                                                            int(inverse), self._stream(t)))
+        return out
+
+    def fft_rows(self, t, rows, n, inverse=False):
+        out = self.torch.empty_like(t)
+        self.capi.check(self.capi.lib().dsp_gpu_fft_batch(t.data_ptr(), out.data_ptr(), n.bit_length() - 1, rows,
+                                                          int(inverse), self.capi.MEM_DEVICE, self._stream(t)))
+        return out
+
+    def transpose_blocks(self, t, blocks, rows, cols):
+        out = self.torch.empty_like(t)
+        self.capi.check(self.capi.lib().dsp_gpu_transpose_blocks(t.data_ptr(), out.data_ptr(), blocks, rows, cols,
+                                                                 self._stream(t)))
+        return out
+
+
+def phases(plan: Plan, rank: int, ops, inverse: bool):
+    """The four local phases of one rank; an all-to-all goes between consecutive phases.
+
+    Every phase maps a flat complex tensor of N/G points to a flat tensor of N/G points laid out as
+    G equal blocks (block g goes to / came from rank g)."""
+    G, R, C = plan.world, plan.rows, plan.cols
+
+    def pack_columns(x):          # [R][G][C] -> [G][R][C]: block g = my rows, rank g's columns
+        return ops.swap_axes(x, R, G, C)
+
+    def transform_n1(recv):       # [N1][C]: FFT over n1; result rows k1 already grouped by destination rank
+        return ops.fft_columns(recv, plan.n1, C, inverse)
+
+    def transform_n2(recv):       # [G][R][C] -> [R][N2] with W_N^{k1 n2}; FFT over n2; pack columns k2 by rank
+        rows = ops.swap_axes(recv, G, R, C, tw_log2n=plan.log2n, row0=rank * R, inverse=inverse)
+        spec = ops.fft_rows(rows, R, plan.n2, inverse)
+        return ops.swap_axes(spec, R, G, C)
+
+    def natural_order(recv):      # [G][R][C] (k1 = g R + r, my k2) -> [C][N1]: X[k1 + N1 k2]
+        return ops.transpose_blocks(recv, G, R, C)
+
+    return [pack_columns, transform_n1, transform_n2, natural_order]
+
+
+def fft_dist(x_local, log2n: int, inverse: bool = False, group=None, ops=None):
+    """Distributed fft0: x_local = this rank's contiguous N/G slice (torch complex64); returns this rank's
+    slice of the natural-order spectrum.  Collective: every rank of `group` must call it."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    plan = make_plan(log2n, world)
+    if x_local.numel() != (1 << log2n) // world:
+        raise ValueError("x_local must hold N / world points")
+    ops = ops or GpuLocalOps()
+    steps = phases(plan, rank, ops, inverse)
+    t = x_local.reshape(-1)
+    for i, step in enumerate(steps):
+        t = step(t)
+        if i + 1 < len(steps) and world > 1:
+            send = torch.view_as_real(t.contiguous())
+            recv = torch.empty_like(send)
+            dist.all_to_all_single(recv, send, group=group)
+            t = torch.view_as_complex(recv)
+    return t
+
+
+def simulate(parts, log2n: int, inverse: bool = False, ops=None):
+    """Run the same phases for len(parts) virtual ranks in this process; the exchanges are block copies.
+    parts[r] = rank r's input slice.  Returns the list of output slices."""
+    import torch
+
+    G = len(parts)
+    plan = make_plan(log2n, G)
+    ops = ops or GpuLocalOps()
+    steps = [phases(plan, r, ops, inverse) for r in range(G)]
+    cur = [p.reshape(-1) for p in parts]
+    for i in range(4):
+        cur = [steps[r][i](cur[r]) for r in range(G)]
+        if i < 3:
+            blocks = [c.reshape(G, -1) for c in cur]
+            cur = [torch.cat([blocks[src][dst] for src in range(G)]) for dst in range(G)]
+    return cur

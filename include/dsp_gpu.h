@@ -120,6 +120,23 @@ int dsp_gpu_iir(const float *x, float *y, size_t channels, size_t n, const doubl
                 const double *b, int poles, double c0, double d0, double *state, int mode, int mem,
                 void *stream);
 
+/*
+ * Local steps of the multi-GPU six-step FFT: one dsp::fft0 (fft.h:31-55) of N = N1*N2 points spread
+ * over G GPUs, n = n1*N2 + n2, k = k1 + N1*k2 (BASELINE config 5).  The three all-to-all exchanges
+ * belong to the host layer (dsp_amd/dist_fft.py, RCCL); these run between them.  DEVICE pointers
+ * only, asynchronous on `stream`, complex fp32 interleaved, in != out.
+ *   dsp_gpu_fft_columns       FFT along axis 0 of a row-major [2^log2n][cols] matrix, natural order,
+ *                             4 <= log2n <= 16, cols a multiple of 256 (16 when log2n <= 8)
+ *   dsp_gpu_swap_axes         out[b][a][c] = in[a][b][c]; when tw_log2n > 0 each element is also
+ *                             multiplied by W^{(tw_row0 + b) * (a*c_extent + c)}, W = e^{+-2 pi i / 2^tw_log2n}
+ *                             (sign by `direction`): the inter-step twiddle fused into the unpack
+ *   dsp_gpu_transpose_blocks  out[col][blk][row] = in[blk][row][col]
+ */
+int dsp_gpu_fft_columns(const void *in, void *out, int log2n, size_t cols, int direction, void *stream);
+int dsp_gpu_swap_axes(const void *in, void *out, size_t a, size_t b, size_t c, int tw_log2n, size_t tw_row0,
+                      int direction, void *stream);
+int dsp_gpu_transpose_blocks(const void *in, void *out, size_t blocks, size_t rows, size_t cols, void *stream);
+
 /* housekeeping */
 int dsp_gpu_device_count(void);
 const char *dsp_gpu_last_error_string(void);

@@ -1,0 +1,190 @@
+"""The multi-GPU six-step FFT (dsp_amd/dist_fft.py): index logic on CPU (virtual ranks and a real
+world_size-2 gloo group, with a numpy stand-in for the local steps), the HIP local steps on the GPU."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import rel_l2
+
+
+class NumpyLocalOps:
+    """Stand-in for GpuLocalOps on CPU torch tensors (TEST ONLY).  Reference convention: FORWARD uses
+    e^{+i...} and nothing normalises, i.e. FORWARD = n * ifft, INVERSE = fft."""
+
+    @staticmethod
+    def _np(t):
+        return t.numpy().astype(np.complex128)
+
+    @staticmethod
+    def _t(a):
+        import torch
+        return torch.from_numpy(np.ascontiguousarray(a).astype(np.complex64).reshape(-1))
+
+    def _dft(self, a, axis, inverse):
+        return np.fft.fft(a, axis=axis) if inverse else np.fft.ifft(a, axis=axis) * a.shape[axis]
+
+    def swap_axes(self, t, a, b, c, tw_log2n=0, row0=0, inverse=False):
+        x = self._np(t).reshape(a, b, c)
+        if tw_log2n:
+            n = 1 << tw_log2n
+            row = (row0 + np.arange(b))[None, :, None]
+            col = (np.arange(a)[:, None, None] * c + np.arange(c)[None, None, :])
+            x = x * np.exp((-2j if inverse else 2j) * np.pi * ((row * col) % n) / n)
+        return self._t(x.transpose(1, 0, 2))
+
+    def fft_columns(self, t, n, cols, inverse=False):
+        return self._t(self._dft(self._np(t).reshape(n, cols), 0, inverse))
+
+    def fft_rows(self, t, rows, n, inverse=False):
+        return self._t(self._dft(self._np(t).reshape(rows, n), 1, inverse))
+
+    def transpose_blocks(self, t, blocks, rows, cols):
+        return self._t(self._np(t).reshape(blocks, rows, cols).transpose(2, 0, 1))
+
+
+def _signal(log2n, seed=2030):
+    rng = np.random.default_rng(seed)
+    n = 1 << log2n
+    return (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+
+
+@pytest.mark.parametrize("log2n,world", [(6, 1), (8, 2), (9, 2), (10, 4), (11, 4), (12, 8)])
+@pytest.mark.parametrize("inverse", [False, True])
+def test_virtual_ranks_cpu(orc, log2n, world, inverse):
+    import torch
+    from dsp_amd import dist_fft
+    x = _signal(log2n)
+    parts = [torch.from_numpy(p.copy()) for p in np.split(x, world)]
+    out = dist_fft.simulate(parts, log2n, inverse, ops=NumpyLocalOps())
+    got = np.concatenate([o.numpy() for o in out])
+    assert rel_l2(got, orc.fft0(x.astype(np.complex128), inverse)) <= 1e-5 * log2n
+
+
+def test_plan_rejects_bad_shapes():
+    from dsp_amd import dist_fft
+    with pytest.raises(ValueError):
+        dist_fft.make_plan(10, 3)
+    with pytest.raises(ValueError):
+        dist_fft.make_plan(4, 8)
+    p = dist_fft.make_plan(30, 8)
+    assert (p.n1, p.n2, p.rows, p.cols) == (1 << 15, 1 << 15, 4096, 4096)
+    assert p.rows * p.cols * 8 == 128 << 20  # one 128 MiB block per peer pair
+
+
+def _gloo_worker(rank, world, rdzv, log2n, outdir):
+    import torch
+    import torch.distributed as dist
+    from dsp_amd import dist_fft, multigpu
+    dist.init_process_group("gloo", init_method=f"file://{rdzv}", rank=rank, world_size=world)
+    x = _signal(log2n)
+    lo, hi = multigpu.shard_range(x.size, rank, world)
+    for inverse in (False, True):
+        mine = torch.from_numpy(x[lo:hi].copy())
+        out = dist_fft.fft_dist(mine, log2n, inverse, ops=NumpyLocalOps())
+        np.save(os.path.join(outdir, f"out_{int(inverse)}_{rank}.npy"), out.numpy())
+    # the bench's timing reduction: max over ranks, sum over ranks
+    assert multigpu.max_over_ranks(1.0 + rank) == float(world)
+    assert multigpu.sum_over_ranks(1.0) == float(world)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2])
+def test_gloo_process_group(tmp_path, orc, world):
+    """The real torch.distributed path (all_to_all_single) with one process per rank, gloo on CPU."""
+    import torch.multiprocessing as mp
+    log2n = 10
+    rdzv = str(tmp_path / "rdzv")
+    mp.spawn(_gloo_worker, args=(world, rdzv, log2n, str(tmp_path)), nprocs=world, join=True)
+    x = _signal(log2n)
+    for inverse in (False, True):
+        got = np.concatenate([np.load(tmp_path / f"out_{int(inverse)}_{r}.npy") for r in range(world)])
+        assert rel_l2(got, orc.fft0(x.astype(np.complex128), inverse)) <= 1e-4
+
+
+def test_shard_range_covers_everything():
+    from dsp_amd import multigpu
+    for total, world in ((65536, 8), (1024, 4), (10, 3), (262144, 2)):
+        spans = [multigpu.shard_range(total, r, world) for r in range(world)]
+        assert spans[0][0] == 0 and spans[-1][1] == total
+        assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+    with pytest.raises(ValueError):
+        multigpu.shard_range(8, 2, 2)
+
+
+# ---- GPU: the HIP local steps ---------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("log2n,world", [(16, 1), (16, 2), (20, 2), (20, 4), (20, 8), (18, 8), (21, 8)])
+def test_virtual_ranks_gpu(orc, dev, log2n, world):
+    import torch
+    from dsp_amd import dist_fft
+    x = _signal(log2n, seed=log2n)
+    for inverse in (False, True):
+        parts = [torch.from_numpy(p.copy()).to(dev) for p in np.split(x, world)]
+        out = dist_fft.simulate(parts, log2n, inverse)
+        got = torch.cat(out).cpu().numpy()
+        assert rel_l2(got, orc.fft0(x.astype(np.complex128), inverse)) <= 1e-5 * log2n
+
+
+@pytest.mark.gpu
+def test_local_steps_against_numpy(dev):
+    import torch
+    from dsp_amd import dist_fft
+    g, ref = dist_fft.GpuLocalOps(), NumpyLocalOps()
+    rng = np.random.default_rng(5)
+    mk = lambda n: (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+    for (a, b, c) in ((4, 8, 256), (1, 16, 64), (8, 512, 128)):
+        x = mk(a * b * c)
+        for tw, row0, inv in ((0, 0, False), (24, 4096 * 3, False), (30, 4096 * 7, True)):
+            got = g.swap_axes(torch.from_numpy(x).to(dev), a, b, c, tw, row0, inv).cpu().numpy()
+            want = ref.swap_axes(torch.from_numpy(x), a, b, c, tw, row0, inv).numpy()
+            assert rel_l2(got, want) <= 1e-6
+    for n, cols in ((16, 256), (256, 16), (1024, 256), (32768, 256), (65536, 256)):
+        x = mk(n * cols)
+        for inv in (False, True):
+            got = g.fft_columns(torch.from_numpy(x).to(dev), n, cols, inv).cpu().numpy()
+            want = ref.fft_columns(torch.from_numpy(x), n, cols, inv).numpy()
+            assert rel_l2(got, want) <= 1e-5 * np.log2(n)
+    for (blocks, rows, cols) in ((1, 32, 32), (3, 50, 70), (8, 128, 512)):
+        x = mk(blocks * rows * cols)
+        got = g.transpose_blocks(torch.from_numpy(x).to(dev), blocks, rows, cols).cpu().numpy()
+        assert np.array_equal(got, ref.transpose_blocks(torch.from_numpy(x), blocks, rows, cols).numpy())
+
+
+@pytest.mark.gpu
+def test_c5_shape_on_one_gpu(dev):
+    """2^24 points over 8 virtual ranks with the real kernels: against the single-GPU transform, plus
+    exact-bin tones (the C5 recipe: tones + small noise)."""
+    import torch
+    from dsp_amd import dist_fft, ops
+    log2n, G = 24, 8
+    n = 1 << log2n
+    g = torch.Generator(device=dev).manual_seed(2030)
+    x = 0.01 * torch.view_as_complex(torch.randn(n, 2, device=dev, generator=g))
+    idx = torch.arange(n, device=dev, dtype=torch.int64)
+    bins = [3, 4097, 65536 + 11, n // 2 + 5, n - 1]
+    for k in bins:
+        ph = ((idx * k) % n).double() * (2 * np.pi / n)
+        x = x + torch.complex(torch.cos(ph), -torch.sin(ph)).to(torch.complex64)
+    out = torch.cat(dist_fft.simulate(list(x.reshape(G, -1)), log2n))
+    single = ops.fft0(x[None])[0]
+    err = torch.linalg.vector_norm((out - single).view(torch.float32).double()) / torch.linalg.vector_norm(single.view(torch.float32).double())
+    assert float(err) <= 1e-5 * log2n
+    top = torch.topk(out.abs(), len(bins)).indices.cpu().tolist()
+    assert sorted(top) == sorted(bins)
+
+
+@pytest.mark.gpu
+def test_nccl_world_of_one(dev, tmp_path, orc):
+    """The torch.distributed code path itself on the GPU (RCCL group of one rank)."""
+    import torch
+    import torch.distributed as dist
+    from dsp_amd import dist_fft
+    dist.init_process_group("nccl", init_method=f"file://{tmp_path}/rdzv", rank=0, world_size=1, device_id=dev)
+    try:
+        x = _signal(16)
+        out = dist_fft.fft_dist(torch.from_numpy(x).to(dev), 16).cpu().numpy()
+        assert rel_l2(out, orc.fft0(x.astype(np.complex128))) <= 1.6e-4
+    finally:
+        dist.destroy_process_group()
