@@ -15,6 +15,24 @@ namespace dspgpu {
 using c32 = float2;
 #define DSP_DEV __device__ __forceinline__
 
+// Streaming (use-once) global accesses: non-temporal loads and stores measured +3 % on a 2 GiB -> 2 GiB
+// copy with this kernel's access pattern (scripts/copy_patterns2.hip).
+DSP_DEV c32 load_stream(const c32 *p) {
+    const float *q = reinterpret_cast<const float *>(p);
+    return make_float2(__builtin_nontemporal_load(q), __builtin_nontemporal_load(q + 1));
+}
+DSP_DEV void store_stream(c32 *p, c32 v) {
+    float *q = reinterpret_cast<float *>(p);
+    __builtin_nontemporal_store(v.x, q);
+    __builtin_nontemporal_store(v.y, q + 1);
+}
+
+// Workgroup -> tile map that lets each XCD stream one contiguous eighth of the batch: workgroups are
+// dealt round-robin over the 8 XCDs (blocks b and b+8 share one), so tile = (b % 8) * chunk + b / 8
+// keeps every XCD's L2 and its HBM channels on neighbouring addresses (+4 % on the same copy).
+// Speed only; any placement gives the same result.  Launch 8 * chunk workgroups, skip tiles >= count.
+DSP_DEV size_t xcd_tile(unsigned block, size_t chunk) { return static_cast<size_t>(block & 7u) * chunk + (block >> 3); }
+
 DSP_DEV c32 cadd(c32 a, c32 b) { return make_float2(a.x + b.x, a.y + b.y); }
 DSP_DEV c32 csub(c32 a, c32 b) { return make_float2(a.x - b.x, a.y - b.y); }
 DSP_DEV c32 cmul(c32 a, c32 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }

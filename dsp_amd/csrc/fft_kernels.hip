@@ -27,16 +27,19 @@ namespace {
 // REAL_IN: rows of real samples, zero padded (fft.h:65-74).  SHIFTED: dsp::shift fused (fft.h:85-94).
 template <int LOG2N, int SIGN, bool REAL_IN, bool SHIFTED>
 __global__ __launch_bounds__(kThreads) void fft_lds_kernel(const void *__restrict__ in_, c32 *__restrict__ out,
-                                                           size_t batch, size_t n_in, size_t in_stride) {
+                                                           size_t batch, size_t n_in, size_t in_stride,
+                                                           size_t tiles, size_t chunk) {
     constexpr int N = 1 << LOG2N;
     constexpr int T = N / kPoints;     // threads per transform
     constexpr int G = kThreads / T;    // transforms per workgroup
     __shared__ c32 lds[kLdsElems];
 
+    const size_t tile = xcd_tile(blockIdx.x, chunk);
+    if (tile >= tiles) return;  // whole workgroup
     const int tid = threadIdx.x;
     const int g = tid / T;
     const int lt = tid % T;
-    const size_t xf = static_cast<size_t>(blockIdx.x) * G + g;
+    const size_t xf = tile * G + g;
     const bool live = xf < batch;
 
     c32 r[kPoints];
@@ -51,7 +54,7 @@ __global__ __launch_bounds__(kThreads) void fft_lds_kernel(const void *__restric
         } else {
             const c32 *src = static_cast<const c32 *>(in_) + xf * N;
 #pragma unroll
-            for (int m = 0; m < kPoints; ++m) r[m] = src[lt + T * m];
+            for (int m = 0; m < kPoints; ++m) r[m] = load_stream(src + lt + T * m);
         }
     } else {
 #pragma unroll
@@ -66,7 +69,7 @@ __global__ __launch_bounds__(kThreads) void fft_lds_kernel(const void *__restric
         for (int m = 0; m < kPoints; ++m) {
             int k = lt + T * m;
             if constexpr (SHIFTED) k = (k + N / 2) & (N - 1);
-            dst[k] = r[m];
+            store_stream(dst + k, r[m]);
         }
     }
 }
@@ -194,13 +197,16 @@ int launch_small(const void *in, c32 *out, size_t batch, size_t n_in, size_t in_
                  hipStream_t s) {
     if constexpr (LOG2N >= 4) {
         constexpr int G = kThreads / ((1 << LOG2N) / kPoints);
-        const size_t blocks = (batch + G - 1) / G;
+        const size_t tiles = (batch + G - 1) / G;
+        const size_t chunk = (tiles + 7) / 8;  // tiles per XCD
+        if (8 * chunk > 0x7fffffffull) return fail(DSP_GPU_EUNSUPPORTED, "batch too large for one launch");
+        const dim3 grid(static_cast<unsigned>(8 * chunk));
         if (direction == DSP_GPU_FORWARD)
-            hipLaunchKernelGGL((fft_lds_kernel<LOG2N, +1, REAL_IN, SHIFTED>), dim3(blocks), dim3(kThreads), 0, s, in,
-                               out, batch, n_in, in_stride);
+            hipLaunchKernelGGL((fft_lds_kernel<LOG2N, +1, REAL_IN, SHIFTED>), grid, dim3(kThreads), 0, s, in, out, batch,
+                               n_in, in_stride, tiles, chunk);
         else
-            hipLaunchKernelGGL((fft_lds_kernel<LOG2N, -1, REAL_IN, SHIFTED>), dim3(blocks), dim3(kThreads), 0, s, in,
-                               out, batch, n_in, in_stride);
+            hipLaunchKernelGGL((fft_lds_kernel<LOG2N, -1, REAL_IN, SHIFTED>), grid, dim3(kThreads), 0, s, in, out, batch,
+                               n_in, in_stride, tiles, chunk);
     } else {
         const size_t blocks = (batch + kThreads - 1) / kThreads;
         if (direction == DSP_GPU_FORWARD)
