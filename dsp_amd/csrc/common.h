@@ -36,6 +36,24 @@ inline int check_launch(const char *what) {
     return DSP_GPU_OK;
 }
 
+// ---- streaming helpers shared by the kernels (device side) ------------------------------------
+#if defined(__HIPCC__)
+typedef float dsp_f32x4 __attribute__((ext_vector_type(4)));
+// use-once global accesses, 16 bytes per lane (p must be 16-byte aligned)
+__device__ __forceinline__ float4 load_stream_f4(const float *p) {
+    const dsp_f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const dsp_f32x4 *>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void store_stream_f4(float *p, float a, float b, float c, float d) {
+    dsp_f32x4 v = {a, b, c, d};
+    __builtin_nontemporal_store(v, reinterpret_cast<dsp_f32x4 *>(p));
+}
+// workgroup -> tile map giving each XCD one contiguous eighth of the tiles (see fft_device.h)
+__device__ __forceinline__ size_t xcd_tile_of(unsigned block, size_t chunk) {
+    return static_cast<size_t>(block & 7u) * chunk + (block >> 3);
+}
+#endif
+
 // Device workspace owned by the library (one growing buffer per device and slot).
 // Slots keep independent users (host staging in/out, FFT scratch, ...) from aliasing.
 enum WorkspaceSlot {

@@ -150,11 +150,13 @@ constexpr int kOsLog2N = 12;
 // outputs [order + b*L, order + (b+1)*L) from inputs [b*L, b*L + 4096), L = 4096 - order.
 __global__ __launch_bounds__(kThreads) void fir_overlap_save_kernel(const float *__restrict__ x, float *__restrict__ y,
                                                                     size_t n, const c32 *__restrict__ hspec, int ntaps,
-                                                                    unsigned pairs_per_channel) {
+                                                                    unsigned pairs_per_channel, size_t tiles, size_t chunk) {
     __shared__ c32 lds[kLdsElems];
     const int tid = threadIdx.x;
-    const size_t ch = blockIdx.x / pairs_per_channel;
-    const unsigned pair = blockIdx.x % pairs_per_channel;
+    const size_t tile = xcd_tile_of(blockIdx.x, chunk);  // each XCD streams a contiguous range of block pairs
+    if (tile >= tiles) return;
+    const size_t ch = tile / pairs_per_channel;
+    const unsigned pair = static_cast<unsigned>(tile % pairs_per_channel);
     const long long order = ntaps - 1;
     const long long L = kOsN - order;
     const long long nn = static_cast<long long>(n);
@@ -166,7 +168,7 @@ __global__ __launch_bounds__(kThreads) void fir_overlap_save_kernel(const float 
 #pragma unroll
     for (int m = 0; m < kPoints; ++m) {
         const long long ia = in_a + tid + kThreads * m, ib = in_b + tid + kThreads * m;
-        r[m] = make_float2(ia < nn ? xc[ia] : 0.0f, ib < nn ? xc[ib] : 0.0f);
+        r[m] = make_float2(ia < nn ? __builtin_nontemporal_load(xc + ia) : 0.0f, ib < nn ? __builtin_nontemporal_load(xc + ib) : 0.0f);
     }
     fft_passes<kOsLog2N, +1>(r, lds, tid, 0);
     constexpr float scale = 1.0f / kOsN;
@@ -186,8 +188,8 @@ __global__ __launch_bounds__(kThreads) void fir_overlap_save_kernel(const float 
         const long long k = tid + kThreads * m;
         if (k < order) continue;  // wrapped (circular) part of the block
         const long long ja = in_a + k, jb = in_b + k;
-        if (ja < nn) yc[ja] = r[m].x;
-        if (jb < nn) yc[jb] = r[m].y;
+        if (ja < nn) __builtin_nontemporal_store(r[m].x, yc + ja);
+        if (jb < nn) __builtin_nontemporal_store(r[m].y, yc + jb);
     }
 }
 
@@ -196,6 +198,13 @@ __global__ __launch_bounds__(kThreads) void fir_overlap_save_kernel(const float 
 // ---------------------------------------------------------------------------------------------
 constexpr int kMaPer = 16;                       // outputs per thread
 constexpr int kMaTile = kThreads * kMaPer;       // 4096 outputs per workgroup
+
+DSP_DEV double shfl_up_f64(double v, int delta) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __shfl_up(lo, delta, 64);
+    hi = __shfl_up(hi, delta, 64);
+    return __hiloint2double(hi, lo);
+}
 DSP_DEV int ma_pad(int i) { return i + ((i >> 4) << 2); }  // 4 pad floats per 16: conflict-free ds_read_b128
 
 // The reference's running sum (filter.h:88-98) starts from x[0..P) and then adds x[i+mid], drops
@@ -203,51 +212,109 @@ DSP_DEV int ma_pad(int i) { return i + ((i >> 4) << 2); }  // 4 pad floats per 1
 //     y[i] = (sum_{k=i-mid}^{i+mid} x[k]  -  (P even ? x[P] : 0)) / P      for mid <= i < n-mid
 // (for odd P the plain centred mean; for even P -- reachable through numPoints(), which does not
 // re-force odd, filter.h:72-74 -- a 2*mid+1 window minus the constant x[P]).  Reproduced as is.
-// LDS: xs[ma_pad(span16)] then chunk sums cs[span16/16].
+//
+// A workgroup stages tile + window samples (aligned down to 4 so the loads are 16 bytes per lane)
+// and turns them into a two-level exclusive prefix sum in LDS: a float prefix inside every chunk of
+// 16 samples (overwriting the samples) plus a DOUBLE prefix over the chunk sums (block scan with wave
+// shuffles).  y[j] = (G[j + window] - G[j]) / P with G[u] = chunk_prefix[u >> 4] + in_chunk[u];
+// consecutive lanes take consecutive outputs, so the LDS reads are conflict-free and the global
+// stores coalesced.  Nothing is carried along the signal, hence none of the reference's accumulated
+// float drift.  LDS: float xs[ma_pad(span)], double pc[chunks], double wave_tot[4].
+template <bool ALIGNED>
 __global__ __launch_bounds__(kThreads) void moving_average_kernel(const float *__restrict__ x, float *__restrict__ y,
-                                                                  size_t n, int npoints, int span16) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *xs = smem;
-    float *cs = smem + ma_pad(span16);
+                                                                  size_t n, int npoints, int span, int cpt) {
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    const int chunks = span >> 4;  // span is a multiple of 16
+    float *xs = smem_f;
+    double *pc = reinterpret_cast<double *>(smem_f + ma_pad(span));
+    double *wave_tot = pc + chunks;
     const int tid = threadIdx.x;
     const size_t ch = blockIdx.y;
     const long long nn = static_cast<long long>(n);
     const long long mid = npoints / 2;
     const int window = 2 * static_cast<int>(mid) + 1;
     const long long out0 = static_cast<long long>(blockIdx.x) * kMaTile;  // first output of the tile
-    const long long seg0 = out0 - mid;                                    // xs[0] = x[seg0]
+    const long long first = out0 - mid;                                   // first sample the tile needs
+    const long long seg0 = first & ~3ll;                                  // staged from here (16-byte aligned)
+    const int shift = static_cast<int>(first - seg0);                     // 0..3
     const float *xc = x + ch * n;
     float *yc = y + ch * n;
     const float corr = ((npoints & 1) == 0 && npoints < nn) ? xc[npoints] : 0.0f;
 
-    for (int u = tid; u < span16; u += kThreads) {
+#pragma unroll 4
+    for (int u = tid * 4; u < span; u += kThreads * 4) {
         const long long g = seg0 + u;
-        xs[ma_pad(u)] = (g >= 0 && g < nn) ? xc[g] : 0.0f;
-    }
-    __syncthreads();
-    for (int c = tid; c < span16 / 16; c += kThreads) {
-        float sum = 0.0f;
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const float4 p = *reinterpret_cast<const float4 *>(xs + ma_pad(16 * c + 4 * v));
-            sum += (p.x + p.y) + (p.z + p.w);
+        float4 v;
+        if (ALIGNED && g >= 0 && g + 3 < nn) {
+            v = load_stream_f4(xc + g);
+        } else {
+            v.x = (g >= 0 && g < nn) ? xc[g] : 0.0f;
+            v.y = (g + 1 >= 0 && g + 1 < nn) ? xc[g + 1] : 0.0f;
+            v.z = (g + 2 >= 0 && g + 2 < nn) ? xc[g + 2] : 0.0f;
+            v.w = (g + 3 >= 0 && g + 3 < nn) ? xc[g + 3] : 0.0f;
         }
-        cs[c] = sum;
+        *reinterpret_cast<float4 *>(xs + ma_pad(u)) = v;
     }
     __syncthreads();
 
-    // thread t: outputs out0 + 16 t + [0,16); window of the first = xs[16 t .. 16 t + window)
-    const int whole = window >> 4, rest = window & 15;
-    float sum = 0.0f;
-    for (int k = 0; k < whole; ++k) sum += cs[tid + k];
-    for (int i = 0; i < rest; ++i) sum += xs[ma_pad(16 * (tid + whole) + i)];
-    const float inv = 1.0f / static_cast<float>(npoints);
+    // thread t owns chunks [t*cpt, (t+1)*cpt): in-chunk exclusive prefixes (float, in place) + chunk sums
+    const int c0 = tid * cpt;
+    double mine = 0.0;
+    for (int k = 0; k < cpt; ++k) {
+        const int c = c0 + k;
+        if (c >= chunks) break;
+        float run = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float4 *p = reinterpret_cast<float4 *>(xs + ma_pad(16 * c + 4 * q));
+            const float4 v = *p;
+            float4 e;
+            e.x = run;
+            e.y = e.x + v.x;
+            e.z = e.y + v.y;
+            e.w = e.z + v.z;
+            run = e.w + v.w;
+            *p = e;
+        }
+        pc[c] = static_cast<double>(run);  // chunk total for now
+        mine += static_cast<double>(run);
+    }
+    // block-wide exclusive scan of the per-thread totals in double
+    double incl = mine;
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const double o = shfl_up_f64(incl, d);
+        if (lane >= d) incl += o;
+    }
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    double running = incl - mine;
+    for (int w = 0; w < wave; ++w) running += wave_tot[w];
+    for (int k = 0; k < cpt; ++k) {
+        const int c = c0 + k;
+        if (c >= chunks) break;
+        const double total = pc[c];
+        pc[c] = running;  // exclusive prefix of the chunk sums
+        running += total;
+    }
+    __syncthreads();
+
+    const double inv = 1.0 / static_cast<double>(npoints);
     const long long hi = (nn - mid > mid + 1) ? nn - mid : mid + 1;  // out[mid] is always written (filter.h:93)
 #pragma unroll
     for (int i = 0; i < kMaPer; ++i) {
-        const long long j = out0 + 16 * tid + i;
-        if (j < nn) yc[j] = (j >= mid && j < hi) ? (sum - corr) * inv : 0.0f;
-        sum += xs[ma_pad(16 * tid + i + window)] - xs[ma_pad(16 * tid + i)];
+        const int jrel = kThreads * i + tid;
+        const long long j = out0 + jrel;
+        if (j >= nn) continue;
+        float v = 0.0f;
+        if (j >= mid && j < hi) {
+            const int lo = jrel + shift, up = lo + window;  // window = staged samples [lo, up)
+            const double sum = (pc[up >> 4] - pc[lo >> 4]) +
+                               (static_cast<double>(xs[ma_pad(up)]) - static_cast<double>(xs[ma_pad(lo)]));
+            v = static_cast<float>((sum - static_cast<double>(corr)) * inv);
+        }
+        __builtin_nontemporal_store(v, yc + j);
     }
 }
 
@@ -283,24 +350,30 @@ int launch_fir_overlap_save(const float *x, float *y, size_t channels, size_t n,
     long long nblocks = (valid + L - 1) / L;
     if (nblocks < 1) nblocks = 1;  // block 0 also zero-fills y[0, order)
     const unsigned pairs = static_cast<unsigned>((nblocks + 1) / 2);
-    const size_t grid = channels * pairs;
-    if (grid > 0x7fffffffull) return fail(DSP_GPU_EUNSUPPORTED, "overlap-save FIR: grid too large");
-    hipLaunchKernelGGL(fir_overlap_save_kernel, dim3(static_cast<unsigned>(grid)), dim3(kThreads), 0, s, x, y, n, d_hspec,
-                       ntaps, pairs);
+    const size_t tiles = channels * pairs;
+    const size_t chunk = (tiles + 7) / 8;
+    if (8 * chunk > 0x7fffffffull) return fail(DSP_GPU_EUNSUPPORTED, "overlap-save FIR: grid too large");
+    hipLaunchKernelGGL(fir_overlap_save_kernel, dim3(static_cast<unsigned>(8 * chunk)), dim3(kThreads), 0, s, x, y, n,
+                       d_hspec, ntaps, pairs, tiles, chunk);
     return check_launch("fir_overlap_save_kernel");
 }
 
 int launch_moving_average(const float *x, float *y, size_t channels, size_t n, int npoints, hipStream_t s) {
-    if (npoints > 16384) return fail(DSP_GPU_EUNSUPPORTED, "moving average: npoints %d > 16384", npoints);
+    if (npoints > 8192) return fail(DSP_GPU_EUNSUPPORTED, "moving average: npoints %d > 8192", npoints);
     if (channels > 65535) return fail(DSP_GPU_EUNSUPPORTED, "moving average: more than 65535 channels per call");
-    const int span16 = ((kMaTile + npoints + 1 + 15) / 16) * 16;  // samples staged per tile (incl. the slide-out reads)
-    const size_t lds_bytes = (static_cast<size_t>(span16 + (span16 / 16) * 4 + 8) + span16 / 16 + 8) * sizeof(float);
+    const int window = 2 * (npoints / 2) + 1;
+    // staged samples: tile + window, + 3 for the aligned start, + 1 so index `up` of the last output exists
+    const int span = ((kMaTile + window + 4 + 15) / 16) * 16;
+    const int chunks = span / 16;
+    const int cpt = (chunks + kThreads - 1) / kThreads;
+    const size_t lds_bytes = static_cast<size_t>(span + (span / 16) * 4) * sizeof(float) + static_cast<size_t>(chunks + 4) * sizeof(double);
     const size_t blocks = (n + kMaTile - 1) / kMaTile;
+    const bool aligned = (n % 4 == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0);
+    auto kern = aligned ? moving_average_kernel<true> : moving_average_kernel<false>;
     if (lds_bytes > 64 * 1024)
-        DSPGPU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(moving_average_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes)));
-    hipLaunchKernelGGL(moving_average_kernel, dim3(blocks, channels), dim3(kThreads), lds_bytes, s, x, y, n, npoints,
-                       span16);
+        DSPGPU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       static_cast<int>(lds_bytes)));
+    hipLaunchKernelGGL(kern, dim3(blocks, channels), dim3(kThreads), lds_bytes, s, x, y, n, npoints, span, cpt);
     return check_launch("moving_average_kernel");
 }
 

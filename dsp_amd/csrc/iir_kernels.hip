@@ -57,7 +57,7 @@ DSP_DEV double iir_step(double x0, double (&xh)[P], double (&vh)[P], const IirCo
 // Run `LEN` samples of one LDS row (stride 1).  STORE: overwrite the row with y.
 template <int P, int LEN, bool STORE>
 DSP_DEV void run_row(float *row, double (&xh)[P], double (&vh)[P], const IirCoef &co) {
-#pragma unroll
+#pragma unroll 16
     for (int i = 0; i < LEN; ++i) {
         const double x0 = static_cast<double>(row[i]);
         const double v = iir_step<P>(x0, xh, vh, co);
@@ -95,7 +95,7 @@ DSP_DEV void batch_load(const float *__restrict__ x, size_t channels, size_t n, 
         if (ch < channels) {
             const float *p = x + ch * n + g;
             if (ALIGNED && g + 3 < n) {
-                v = *reinterpret_cast<const float4 *>(p);
+                v = load_stream_f4(p);
             } else {
                 if (g < n) v.x = p[0];
                 if (g + 1 < n) v.y = p[1];
@@ -110,12 +110,14 @@ DSP_DEV void batch_load(const float *__restrict__ x, size_t channels, size_t n, 
 template <int P, bool ALIGNED>
 __global__ __launch_bounds__(kWave) void iir_batch_kernel(const float *__restrict__ x, float *__restrict__ y,
                                                            size_t channels, size_t n, IirCoef co,
-                                                           double *__restrict__ state) {
+                                                           double *__restrict__ state, size_t groups, size_t chunk) {
     __shared__ float tile[kWave * kBtPad];
     constexpr int kLanesPerRow = kBt / 4;
     constexpr int kRowsPerIter = kWave / kLanesPerRow;
     const int lane = threadIdx.x;
-    const size_t ch0 = static_cast<size_t>(blockIdx.x) * kWave;
+    const size_t group = xcd_tile_of(blockIdx.x, chunk);  // each XCD owns a contiguous range of channels
+    if (group >= groups) return;
+    const size_t ch0 = group * kWave;
     const size_t ch = ch0 + lane;
     const bool live = ch < channels;
 
@@ -155,7 +157,7 @@ __global__ __launch_bounds__(kWave) void iir_batch_kernel(const float *__restric
             const float *src = tile + (it * kRowsPerIter + lane / kLanesPerRow) * kBtPad + (lane % kLanesPerRow) * 4;
             float *p = y + c * n + g;
             if (ALIGNED && g + 3 < n) {
-                *reinterpret_cast<float4 *>(p) = make_float4(src[0], src[1], src[2], src[3]);
+                store_stream_f4(p, src[0], src[1], src[2], src[3]);
             } else {
                 p[0] = src[0];
                 if (g + 1 < n) p[1] = src[1];
@@ -185,6 +187,13 @@ constexpr int kLevels = 8;          // log2(kSt)
 
 enum ScanMode { SCAN_REDUCE = 0, SCAN_APPLY = 1, SCAN_FUSED = 2 };
 
+DSP_DEV double shfl_up_f64(double v, int delta) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __shfl_up(lo, delta, 64);
+    hi = __shfl_up(hi, delta, 64);
+    return __hiloint2double(hi, lo);
+}
+
 // s += M * o   (M row-major P x P)
 template <int P>
 DSP_DEV void mat_acc(double (&s)[P], const double *__restrict__ M, const double (&o)[P]) {
@@ -203,11 +212,13 @@ __global__ __launch_bounds__(kSt) void iir_scan_kernel(const float *__restrict__
                                                        IirCoef co, const double *__restrict__ mats,
                                                        const double *__restrict__ state_in,
                                                        double *__restrict__ state_out, double *__restrict__ tile_z,
-                                                       const double *__restrict__ tile_c, unsigned ntiles, int warm) {
+                                                       const double *__restrict__ tile_c, unsigned ntiles, int warm,
+                                                       int levels) {
     __shared__ float xs[(kSt + 1) * kRowPad];
-    __shared__ double sbuf[P * kSt];
+    __shared__ double sbuf[4 * P];  // wave aggregates
     const int tid = threadIdx.x;
-    const unsigned tile = blockIdx.x;
+    const unsigned tile = static_cast<unsigned>(xcd_tile_of(blockIdx.x, (ntiles + 7u) / 8u));  // contiguous time range per XCD
+    if (tile >= ntiles) return;
     const size_t ch = blockIdx.y;
     const float *xc = x + ch * n;
     float *yc = y + ch * n;
@@ -228,7 +239,7 @@ __global__ __launch_bounds__(kSt) void iir_scan_kernel(const float *__restrict__
         const size_t g = start + u;
         float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         if (ALIGNED && g + 3 < n) {
-            v = *reinterpret_cast<const float4 *>(xc + g);
+            v = load_stream_f4(xc + g);
         } else {
             if (g < n) v.x = xc[g];
             if (g + 1 < n) v.y = xc[g + 1];
@@ -272,20 +283,52 @@ __global__ __launch_bounds__(kSt) void iir_scan_kernel(const float *__restrict__
     }
     if (tid == 0) mat_acc<P>(vh, mats, carry);
 
-    // phase B: inclusive Kogge-Stone scan of the row-end states, S_t += A^(32*2^j) S_{t-2^j}
+    // phase B: inclusive scan of the row-end states, S_l = Z_l + A^32 S_{l-1}.  Inside a wave it is a
+    // Kogge-Stone scan over lanes with shuffles (S_l += A^(32*2^j) S_{l-2^j}, no barrier); `levels` is
+    // the number of doubling levels whose matrix is not negligible (host: ||A^(32*2^j)|| > 2^-60), so a
+    // fast-decaying filter stops early.  Across the 4 waves: wave aggregates go through LDS once, the
+    // carry into wave w is c_w = agg_{w-1} + A^(32*64) c_{w-1}, and its effect on lane l,
+    // A^(32(l+1)) c_w, is the same scan applied to (A^32 c_w, 0, 0, ...).
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wave_levels = levels < 6 ? levels : 6;
 #pragma unroll 1
-    for (int j = 0; j < kLevels; ++j) {
+    for (int j = 0; j < wave_levels; ++j) {
+        double o[P];
 #pragma unroll
-        for (int i = 0; i < P; ++i) sbuf[i * kSt + tid] = vh[i];
-        __syncthreads();
-        const int off = 1 << j;
-        if (tid >= off) {
+        for (int i = 0; i < P; ++i) o[i] = shfl_up_f64(vh[i], 1 << j);
+        if (lane >= (1 << j)) mat_acc<P>(vh, mats + j * P * P, o);
+    }
+    if (lane == 63)
+#pragma unroll
+        for (int i = 0; i < P; ++i) sbuf[wave * P + i] = vh[i];
+    __syncthreads();
+    double cw[P];  // true state at the end of the previous wave (the tile carry for wave 0)
+#pragma unroll
+    for (int i = 0; i < P; ++i) cw[i] = carry[i];
+    if (wave > 0) {
+#pragma unroll
+        for (int i = 0; i < P; ++i) cw[i] = 0.0;
+        for (int w = 0; w < wave; ++w) {
+            double nxt[P];
+#pragma unroll
+            for (int i = 0; i < P; ++i) nxt[i] = sbuf[w * P + i];
+            if (levels > 6) mat_acc<P>(nxt, mats + 6 * P * P, cw);
+#pragma unroll
+            for (int i = 0; i < P; ++i) cw[i] = nxt[i];
+        }
+        double v[P];
+#pragma unroll
+        for (int i = 0; i < P; ++i) v[i] = 0.0;
+        if (lane == 0) mat_acc<P>(v, mats, cw);
+#pragma unroll 1
+        for (int j = 0; j < wave_levels; ++j) {
             double o[P];
 #pragma unroll
-            for (int i = 0; i < P; ++i) o[i] = sbuf[i * kSt + tid - off];
-            mat_acc<P>(vh, mats + j * P * P, o);
+            for (int i = 0; i < P; ++i) o[i] = shfl_up_f64(v[i], 1 << j);
+            if (lane >= (1 << j)) mat_acc<P>(v, mats + j * P * P, o);
         }
-        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < P; ++i) vh[i] += v[i];
     }
     if (MODE == SCAN_REDUCE) {
         if (tid == kSt - 1)
@@ -293,15 +336,17 @@ __global__ __launch_bounds__(kSt) void iir_scan_kernel(const float *__restrict__
             for (int i = 0; i < P; ++i) tile_z[(ch * ntiles + tile) * P + i] = vh[i];
         return;
     }
-#pragma unroll
-    for (int i = 0; i < P; ++i) sbuf[i * kSt + tid] = vh[i];
-    __syncthreads();
 
-    // phase C: true start state = inclusive state of the row before (the tile carry for row 0)
+    // phase C: true start state = inclusive state of the row before (the carry for the first row of a wave)
+    {
+        double prev[P];
 #pragma unroll
-    for (int i = 0; i < P; ++i) {
-        xh[i] = xh0[i];
-        vh[i] = tid == 0 ? carry[i] : sbuf[i * kSt + tid - 1];
+        for (int i = 0; i < P; ++i) prev[i] = shfl_up_f64(vh[i], 1);
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            xh[i] = xh0[i];
+            vh[i] = lane == 0 ? cw[i] : prev[i];
+        }
     }
     const size_t g0 = start + static_cast<size_t>(tid) * kRow;
     if (g0 + kRow <= n) {
@@ -324,7 +369,7 @@ __global__ __launch_bounds__(kSt) void iir_scan_kernel(const float *__restrict__
         if (g < out_begin || g >= n) continue;
         const float *src = xs + (u / kRow + 1) * kRowPad + (u % kRow);
         if (ALIGNED && g + 3 < n) {
-            *reinterpret_cast<float4 *>(yc + g) = make_float4(src[0], src[1], src[2], src[3]);
+            store_stream_f4(yc + g, src[0], src[1], src[2], src[3]);
         } else {
             yc[g] = src[0];
             if (g + 1 < n) yc[g + 1] = src[1];
@@ -470,9 +515,12 @@ int scan_dispatch(const float *x, float *y, size_t channels, size_t n, const Iir
     std::vector<double> table(static_cast<size_t>(9 + 9) * P * P, 0.0);
     Mat m = mat_pow(A, kRow, P);
     double amp = 0.0;  // largest carry matrix the scan multiplies a state with
+    int levels = kLevels + 1;  // doubling levels whose matrix still matters (norm > 2^-60)
     for (int j = 0; j <= kLevels; ++j) {
         store_mat(table, j, m, P);
-        amp = std::max(amp, mat_norm_inf(m, P));
+        const double nrm = mat_norm_inf(m, P);
+        amp = std::max(amp, nrm);
+        if (nrm <= 0x1p-60 && levels > j) levels = j;
         if (j < kLevels) m = mat_mul(m, m, P);
     }
     const Mat MT = m;  // A^8192
@@ -530,10 +578,10 @@ int scan_dispatch(const float *x, float *y, size_t channels, size_t n, const Iir
     // pageable source: the runtime stages the bytes before returning, `table` may go out of scope
     DSPGPU_HIP(hipMemcpyAsync(d_table, table.data(), table.size() * sizeof(double), hipMemcpyHostToDevice, s));
 
-    const dim3 grid(ntiles, static_cast<unsigned>(channels));
+    const dim3 grid(8u * ((ntiles + 7u) / 8u), static_cast<unsigned>(channels));
     if (fused) {
         hipLaunchKernelGGL((iir_scan_kernel<P, SCAN_FUSED, ALIGNED>), grid, dim3(kSt), 0, s, x, y, n, co, d_table,
-                           state_in, state, nullptr, nullptr, ntiles, warm);
+                           state_in, state, nullptr, nullptr, ntiles, warm, levels);
         return check_launch("iir_scan_kernel<fused>");
     }
     void *z_v = nullptr, *c_v = nullptr;
@@ -542,23 +590,24 @@ int scan_dispatch(const float *x, float *y, size_t channels, size_t n, const Iir
     if (int rc = workspace(WS_SCRATCH_B, carry_bytes, &c_v)) return rc;
     double *tz = static_cast<double *>(z_v), *tc = static_cast<double *>(c_v);
     hipLaunchKernelGGL((iir_scan_kernel<P, SCAN_REDUCE, ALIGNED>), grid, dim3(kSt), 0, s, x, y, n, co, d_table,
-                       state_in, nullptr, tz, nullptr, ntiles, 0);
+                       state_in, nullptr, tz, nullptr, ntiles, 0, levels);
     if (int rc = check_launch("iir_scan_kernel<reduce>")) return rc;
     hipLaunchKernelGGL((iir_carry_kernel<P>), dim3(static_cast<unsigned>(channels)), dim3(kSt), 0, s, tz, tc,
                        d_table + static_cast<size_t>(9) * P * P, state_in, ntiles, G);
     if (int rc = check_launch("iir_carry_kernel")) return rc;
     hipLaunchKernelGGL((iir_scan_kernel<P, SCAN_APPLY, ALIGNED>), grid, dim3(kSt), 0, s, x, y, n, co, d_table,
-                       state_in, state, nullptr, tc, ntiles, 0);
+                       state_in, state, nullptr, tc, ntiles, 0, levels);
     return check_launch("iir_scan_kernel<apply>");
 }
 
 template <int P, bool ALIGNED>
 int batch_dispatch(const float *x, float *y, size_t channels, size_t n, const IirCoef &co, double *state,
                    hipStream_t s) {
-    const size_t blocks = (channels + kWave - 1) / kWave;
-    if (blocks > 0x7fffffffull) return fail(DSP_GPU_EUNSUPPORTED, "IIR batch: too many channels");
-    hipLaunchKernelGGL((iir_batch_kernel<P, ALIGNED>), dim3(static_cast<unsigned>(blocks)), dim3(kWave), 0, s, x, y,
-                       channels, n, co, state);
+    const size_t groups = (channels + kWave - 1) / kWave;
+    const size_t chunk = (groups + 7) / 8;
+    if (8 * chunk > 0x7fffffffull) return fail(DSP_GPU_EUNSUPPORTED, "IIR batch: too many channels");
+    hipLaunchKernelGGL((iir_batch_kernel<P, ALIGNED>), dim3(static_cast<unsigned>(8 * chunk)), dim3(kWave), 0, s, x, y,
+                       channels, n, co, state, groups, chunk);
     return check_launch("iir_batch_kernel");
 }
 

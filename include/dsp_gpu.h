@@ -97,7 +97,7 @@ int dsp_gpu_convolve(const float *x, float *y, size_t channels, size_t n, const 
  * for mid <= i < n-mid, zero elsewhere -- for odd npoints the plain centred mean; for even
  * npoints (reachable through numPoints(), filter.h:72-74) exactly what the reference's running
  * sum evaluates to.  Windows are summed directly (no running sum along the signal), so the
- * result does not carry the reference's accumulated rounding drift.  n >= npoints >= 1.
+ * result does not carry the reference's accumulated rounding drift.  n >= npoints >= 1, npoints <= 8192.
  */
 int dsp_gpu_moving_average(const float *x, float *y, size_t channels, size_t n, int npoints,
                            int mem, void *stream);

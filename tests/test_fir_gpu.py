@@ -141,7 +141,7 @@ def test_mavg_kat(ops, dev, golden):
 
 
 @pytest.mark.parametrize("channels,n,pts", [(1, 8192, 511), (1, 8192, 8), (3, 1000, 511), (2, 511, 511), (2, 64, 1),
-                                            (2, 30000, 4096), (2, 30000, 4097), (3, 9001, 100), (1, 8, 8), (1, 9, 8),
+                                            (2, 30000, 4096), (2, 30000, 4097), (1, 30000, 8192), (3, 9001, 100), (1, 8, 8), (1, 9, 8),
                                             (2, 5000, 2), (2, 5000, 3)])
 def test_mavg_vs_oracle(ops, dev, orc, channels, n, pts):
     import torch
