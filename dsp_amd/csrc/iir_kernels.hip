@@ -23,6 +23,8 @@
 //                      rounding; 8 B/sample * T/(T-W)).
 //   iir_carry_kernel   scan of the per-tile end states (one workgroup per channel).
 #include <cmath>
+#include <cstring>
+#include <mutex>
 #include <vector>
 
 #include "common.h"
@@ -61,7 +63,7 @@ DSP_DEV void run_row(float *row, double (&xh)[P], double (&vh)[P], const IirCoef
     for (int i = 0; i < LEN; ++i) {
         const double x0 = static_cast<double>(row[i]);
         const double v = iir_step<P>(x0, xh, vh, co);
-        if (STORE) row[i] = static_cast<float>(v * co.c0 + x0 * co.d0);
+        if (STORE) row[i] = static_cast<float>(fma(v, co.c0, x0 * co.d0));
     }
 }
 
@@ -71,7 +73,7 @@ DSP_DEV void run_row_partial(float *row, int count, double (&xh)[P], double (&vh
     for (int i = 0; i < count; ++i) {
         const double x0 = static_cast<double>(row[i]);
         const double v = iir_step<P>(x0, xh, vh, co);
-        if (STORE) row[i] = static_cast<float>(v * co.c0 + x0 * co.d0);
+        if (STORE) row[i] = static_cast<float>(fma(v, co.c0, x0 * co.d0));
     }
 }
 
@@ -194,28 +196,140 @@ DSP_DEV double shfl_up_f64(double v, int delta) {
     return __hiloint2double(hi, lo);
 }
 
-// s += M * o   (M row-major P x P)
-template <int P>
-DSP_DEV void mat_acc(double (&s)[P], const double *__restrict__ M, const double (&o)[P]) {
+// ---- double-double helpers (error-free transformations) -------------------------------------------
+// Contraction must stay OFF around them: with -ffp-contract=fast the backend turns `p + e` (p = x.hi*y.hi
+// rounded, e = its exact error + cross terms) into fma(x.hi, y.hi, e), which adds the product's rounding
+// error twice and silently degrades the result to plain double (found in the ISA).  The pragma alone does
+// not stop the backend, so the Makefile builds this file with -ffp-contract=off; the recursion itself
+// calls fma() explicitly.
+struct DD {
+    double hi, lo;
+};
+__host__ __device__ inline DD dd_two_sum(double a, double b) {
+#pragma clang fp contract(off)
+
+    const double s = a + b, bb = s - a;
+    return DD{s, (a - (s - bb)) + (b - bb)};
+}
+__host__ __device__ inline DD dd_add(DD x, DD y) {
+#pragma clang fp contract(off)
+
+    const DD s = dd_two_sum(x.hi, y.hi);
+    const double e = s.lo + (x.lo + y.lo);
+    const double hi = s.hi + e;
+    return DD{hi, e - (hi - s.hi)};
+}
+__host__ __device__ inline DD dd_mul(DD x, DD y) {
+#pragma clang fp contract(off)
+
+    const double p = x.hi * y.hi;
+    double e = fma(x.hi, y.hi, -p);
+    e += x.hi * y.lo + x.lo * y.hi;
+    const double hi = p + e;
+    return DD{hi, e - (hi - p)};
+}
+
+// A feedback state (v[t-1..t-P]) carried across rows / tiles: plain double, or double-double when the
+// companion-matrix powers are too large for double carries (poles clustered at the unit circle).
+template <int P, bool WIDE>
+struct SVec {
+    double hi[P];
+    double lo[WIDE ? P : 1];
+};
+template <int P, bool WIDE>
+constexpr int kWords = WIDE ? 2 * P : P;  // doubles per stored state / matrix row block
+
+template <int P, bool WIDE>
+DSP_DEV void sv_zero(SVec<P, WIDE> &s) {
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        s.hi[i] = 0.0;
+        if (WIDE) s.lo[i] = 0.0;
+    }
+}
+template <int P, bool WIDE>
+DSP_DEV void sv_load(SVec<P, WIDE> &s, const double *p) {  // layout: P hi [, P lo]
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        s.hi[i] = p[i];
+        if (WIDE) s.lo[i] = p[P + i];
+    }
+}
+template <int P, bool WIDE>
+DSP_DEV void sv_store(const SVec<P, WIDE> &s, double *p) {
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        p[i] = s.hi[i];
+        if (WIDE) p[P + i] = s.lo[i];
+    }
+}
+template <int P, bool WIDE>
+DSP_DEV SVec<P, WIDE> sv_shfl_up(const SVec<P, WIDE> &s, int delta) {
+    SVec<P, WIDE> o;
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        o.hi[i] = shfl_up_f64(s.hi[i], delta);
+        if (WIDE) o.lo[i] = shfl_up_f64(s.lo[i], delta);
+    }
+    return o;
+}
+// s += M * o.  M: P*P doubles (hi) [followed by P*P doubles (lo)], row-major.
+template <int P, bool WIDE>
+DSP_DEV void sv_mat_acc(SVec<P, WIDE> &s, const double *__restrict__ M, const SVec<P, WIDE> &o) {
 #pragma unroll
     for (int r = 0; r < P; ++r) {
-        double acc = s[r];
+        if (WIDE) {
+            DD acc{s.hi[r], s.lo[r]};
 #pragma unroll
-        for (int c = 0; c < P; ++c) acc = fma(M[r * P + c], o[c], acc);
-        s[r] = acc;
+            for (int c = 0; c < P; ++c)
+                acc = dd_add(acc, dd_mul(DD{M[r * P + c], M[P * P + r * P + c]}, DD{o.hi[c], o.lo[c]}));
+            s.hi[r] = acc.hi;
+            s.lo[r] = acc.lo;
+        } else {
+            double acc = s.hi[r];
+#pragma unroll
+            for (int c = 0; c < P; ++c) acc = fma(M[r * P + c], o.hi[c], acc);
+            s.hi[r] = acc;
+        }
+    }
+}
+template <int P, bool WIDE>
+DSP_DEV void sv_add(SVec<P, WIDE> &s, const SVec<P, WIDE> &o) {
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        if (WIDE) {
+            const DD r = dd_add(DD{s.hi[i], s.lo[i]}, DD{o.hi[i], o.lo[i]});
+            s.hi[i] = r.hi;
+            s.lo[i] = r.lo;
+        } else {
+            s.hi[i] += o.hi[i];
+        }
     }
 }
 
-// mats: [0..8] = A^(32*2^j) (j = 8 is the whole-tile matrix), companion A in the vh ordering.
-template <int P, int MODE, bool ALIGNED>
+// Inclusive Kogge-Stone scan over the lanes of a wave: S_l += A^(32*2^j) S_{l-2^j}, j < levels (<= 6).
+template <int P, bool WIDE>
+DSP_DEV void wave_scan(SVec<P, WIDE> &S, const double *__restrict__ mats, int levels, int lane) {
+    constexpr int MS = kWords<P, WIDE> * P;  // doubles per matrix slot
+#pragma unroll 1
+    for (int j = 0; j < levels; ++j) {
+        const SVec<P, WIDE> o = sv_shfl_up<P, WIDE>(S, 1 << j);
+        if (lane >= (1 << j)) sv_mat_acc<P, WIDE>(S, mats + j * MS, o);
+    }
+}
+
+// mats: slots [0..8] = A^(32*2^j) (j = 8 is the whole-tile matrix), companion A in the vh ordering.
+template <int P, int MODE, bool ALIGNED, bool WIDE>
 __global__ __launch_bounds__(kSt) void iir_scan_kernel(const float *__restrict__ x, float *__restrict__ y, size_t n,
                                                        IirCoef co, const double *__restrict__ mats,
                                                        const double *__restrict__ state_in,
                                                        double *__restrict__ state_out, double *__restrict__ tile_z,
                                                        const double *__restrict__ tile_c, unsigned ntiles, int warm,
                                                        int levels) {
+    constexpr int W = kWords<P, WIDE>;
+    constexpr int MS = W * P;
     __shared__ float xs[(kSt + 1) * kRowPad];
-    __shared__ double sbuf[4 * P];  // wave aggregates
+    __shared__ double sbuf[4 * W];  // wave aggregates
     const int tid = threadIdx.x;
     const unsigned tile = static_cast<unsigned>(xcd_tile_of(blockIdx.x, (ntiles + 7u) / 8u));  // contiguous time range per XCD
     if (tile >= ntiles) return;
@@ -272,80 +386,61 @@ __global__ __launch_bounds__(kSt) void iir_scan_kernel(const float *__restrict__
         vh[i] = 0.0;
     }
     run_row<P, kRow, false>(row, xh, vh, co);
+    SVec<P, WIDE> S;
+    sv_zero<P, WIDE>(S);
+#pragma unroll
+    for (int i = 0; i < P; ++i) S.hi[i] = vh[i];
 
     // carry into the tile
-    double carry[P];
+    SVec<P, WIDE> carry;
+    sv_zero<P, WIDE>(carry);
+    if (MODE == SCAN_APPLY) sv_load<P, WIDE>(carry, tile_c + (ch * ntiles + tile) * W);
+    else if (MODE == SCAN_FUSED && tile == 0 && sin_c)
 #pragma unroll
-    for (int i = 0; i < P; ++i) {
-        if (MODE == SCAN_APPLY) carry[i] = tile_c[(ch * ntiles + tile) * P + i];
-        else if (MODE == SCAN_FUSED && tile == 0 && sin_c) carry[i] = sin_c[P + i];
-        else carry[i] = 0.0;
-    }
-    if (tid == 0) mat_acc<P>(vh, mats, carry);
+        for (int i = 0; i < P; ++i) carry.hi[i] = sin_c[P + i];
+    if (tid == 0) sv_mat_acc<P, WIDE>(S, mats, carry);
 
     // phase B: inclusive scan of the row-end states, S_l = Z_l + A^32 S_{l-1}.  Inside a wave it is a
-    // Kogge-Stone scan over lanes with shuffles (S_l += A^(32*2^j) S_{l-2^j}, no barrier); `levels` is
-    // the number of doubling levels whose matrix is not negligible (host: ||A^(32*2^j)|| > 2^-60), so a
-    // fast-decaying filter stops early.  Across the 4 waves: wave aggregates go through LDS once, the
-    // carry into wave w is c_w = agg_{w-1} + A^(32*64) c_{w-1}, and its effect on lane l,
-    // A^(32(l+1)) c_w, is the same scan applied to (A^32 c_w, 0, 0, ...).
+    // Kogge-Stone scan over lanes with shuffles (no barrier); `levels` is the number of doubling levels
+    // whose matrix is not negligible (host: ||A^(32*2^j)|| > 2^-60), so a fast-decaying filter stops
+    // early.  Across the 4 waves: wave aggregates go through LDS once, the carry into wave w is
+    // c_w = agg_{w-1} + A^(32*64) c_{w-1}, and its effect on lane l, A^(32(l+1)) c_w, is the same scan
+    // applied to (A^32 c_w, 0, 0, ...).
     const int lane = tid & 63, wave = tid >> 6;
     const int wave_levels = levels < 6 ? levels : 6;
-#pragma unroll 1
-    for (int j = 0; j < wave_levels; ++j) {
-        double o[P];
-#pragma unroll
-        for (int i = 0; i < P; ++i) o[i] = shfl_up_f64(vh[i], 1 << j);
-        if (lane >= (1 << j)) mat_acc<P>(vh, mats + j * P * P, o);
-    }
-    if (lane == 63)
-#pragma unroll
-        for (int i = 0; i < P; ++i) sbuf[wave * P + i] = vh[i];
+    wave_scan<P, WIDE>(S, mats, wave_levels, lane);
+    if (lane == 63) sv_store<P, WIDE>(S, sbuf + wave * W);
     __syncthreads();
-    double cw[P];  // true state at the end of the previous wave (the tile carry for wave 0)
-#pragma unroll
-    for (int i = 0; i < P; ++i) cw[i] = carry[i];
+    SVec<P, WIDE> cw = carry;  // true state at the end of the previous wave (the tile carry for wave 0)
     if (wave > 0) {
-#pragma unroll
-        for (int i = 0; i < P; ++i) cw[i] = 0.0;
+        sv_zero<P, WIDE>(cw);
         for (int w = 0; w < wave; ++w) {
-            double nxt[P];
-#pragma unroll
-            for (int i = 0; i < P; ++i) nxt[i] = sbuf[w * P + i];
-            if (levels > 6) mat_acc<P>(nxt, mats + 6 * P * P, cw);
-#pragma unroll
-            for (int i = 0; i < P; ++i) cw[i] = nxt[i];
+            SVec<P, WIDE> nxt;
+            sv_load<P, WIDE>(nxt, sbuf + w * W);
+            if (levels > 6) sv_mat_acc<P, WIDE>(nxt, mats + 6 * MS, cw);
+            cw = nxt;
         }
-        double v[P];
-#pragma unroll
-        for (int i = 0; i < P; ++i) v[i] = 0.0;
-        if (lane == 0) mat_acc<P>(v, mats, cw);
-#pragma unroll 1
-        for (int j = 0; j < wave_levels; ++j) {
-            double o[P];
-#pragma unroll
-            for (int i = 0; i < P; ++i) o[i] = shfl_up_f64(v[i], 1 << j);
-            if (lane >= (1 << j)) mat_acc<P>(v, mats + j * P * P, o);
-        }
-#pragma unroll
-        for (int i = 0; i < P; ++i) vh[i] += v[i];
+        SVec<P, WIDE> v;
+        sv_zero<P, WIDE>(v);
+        if (lane == 0) sv_mat_acc<P, WIDE>(v, mats, cw);
+        wave_scan<P, WIDE>(v, mats, wave_levels, lane);
+        sv_add<P, WIDE>(S, v);
     }
     if (MODE == SCAN_REDUCE) {
-        if (tid == kSt - 1)
-#pragma unroll
-            for (int i = 0; i < P; ++i) tile_z[(ch * ntiles + tile) * P + i] = vh[i];
+        if (tid == kSt - 1) sv_store<P, WIDE>(S, tile_z + (ch * ntiles + tile) * W);
         return;
     }
 
-    // phase C: true start state = inclusive state of the row before (the carry for the first row of a wave)
+    // phase C: true start state = inclusive state of the row before (the carry for the first row of a
+    // wave), rounded to double exactly as the sequential recursion would hold it
     {
-        double prev[P];
-#pragma unroll
-        for (int i = 0; i < P; ++i) prev[i] = shfl_up_f64(vh[i], 1);
+        const SVec<P, WIDE> prev = sv_shfl_up<P, WIDE>(S, 1);
 #pragma unroll
         for (int i = 0; i < P; ++i) {
             xh[i] = xh0[i];
-            vh[i] = lane == 0 ? cw[i] : prev[i];
+            const double ph = lane == 0 ? cw.hi[i] : prev.hi[i];
+            const double pl = WIDE ? (lane == 0 ? cw.lo[i] : prev.lo[i]) : 0.0;
+            vh[i] = ph + pl;
         }
     }
     const size_t g0 = start + static_cast<size_t>(tid) * kRow;
@@ -380,80 +475,84 @@ __global__ __launch_bounds__(kSt) void iir_scan_kernel(const float *__restrict__
 }
 
 // Exclusive scan of the tile end states: C_0 = initial state, C_k = Z_{k-1} + MT C_{k-1}.
-// mats2: [0] = MT = A^8192, [1 + j] = MT^(G * 2^j); thread t owns tiles [t G, (t+1) G).
-template <int P>
+// mats2: slot [0] = MT = A^8192, [1 + j] = MT^(G * 2^j); thread t owns tiles [t G, (t+1) G).
+template <int P, bool WIDE>
 __global__ __launch_bounds__(kSt) void iir_carry_kernel(const double *__restrict__ tile_z, double *__restrict__ tile_c,
                                                          const double *__restrict__ mats2,
                                                          const double *__restrict__ state_in, unsigned ntiles,
                                                          unsigned G) {
-    __shared__ double sbuf[P * kSt];
+    constexpr int W = kWords<P, WIDE>;
+    constexpr int MS = W * P;
+    __shared__ double sbuf[W * kSt];
     const int tid = threadIdx.x;
     const size_t ch = blockIdx.x;
-    const double *z = tile_z + ch * ntiles * P;
-    double *c = tile_c + ch * ntiles * P;
+    const double *z = tile_z + ch * ntiles * W;
+    double *c = tile_c + ch * ntiles * W;
     const unsigned k0 = tid * G, k1 = min(ntiles, k0 + G);
 
-    double s[P];
+    SVec<P, WIDE> s;
+    sv_zero<P, WIDE>(s);
+    if (tid == 0 && state_in)
 #pragma unroll
-    for (int i = 0; i < P; ++i) s[i] = (tid == 0 && state_in) ? state_in[ch * 2 * P + P + i] : 0.0;
-    double first[P];
-#pragma unroll
-    for (int i = 0; i < P; ++i) first[i] = s[i];
+        for (int i = 0; i < P; ++i) s.hi[i] = state_in[ch * 2 * P + P + i];
+    const SVec<P, WIDE> first = s;
     for (unsigned k = k0; k < k1; ++k) {
-        double nxt[P];
-#pragma unroll
-        for (int i = 0; i < P; ++i) nxt[i] = z[k * P + i];
-        mat_acc<P>(nxt, mats2, s);
-#pragma unroll
-        for (int i = 0; i < P; ++i) s[i] = nxt[i];
+        SVec<P, WIDE> nxt;
+        sv_load<P, WIDE>(nxt, z + static_cast<size_t>(k) * W);
+        sv_mat_acc<P, WIDE>(nxt, mats2, s);
+        s = nxt;
     }
 #pragma unroll 1
     for (int j = 0; j < kLevels; ++j) {
 #pragma unroll
-        for (int i = 0; i < P; ++i) sbuf[i * kSt + tid] = s[i];
+        for (int i = 0; i < W; ++i) sbuf[i * kSt + tid] = i < P ? s.hi[i] : s.lo[WIDE ? i - P : 0];
         __syncthreads();
         const int off = 1 << j;
         if (tid >= off) {
-            double o[P];
+            SVec<P, WIDE> o;
 #pragma unroll
-            for (int i = 0; i < P; ++i) o[i] = sbuf[i * kSt + tid - off];
-            mat_acc<P>(s, mats2 + (1 + j) * P * P, o);
+            for (int i = 0; i < P; ++i) {
+                o.hi[i] = sbuf[i * kSt + tid - off];
+                if (WIDE) o.lo[i] = sbuf[(P + i) * kSt + tid - off];
+            }
+            sv_mat_acc<P, WIDE>(s, mats2 + (1 + j) * MS, o);
         }
         __syncthreads();
     }
 #pragma unroll
-    for (int i = 0; i < P; ++i) sbuf[i * kSt + tid] = s[i];
+    for (int i = 0; i < W; ++i) sbuf[i * kSt + tid] = i < P ? s.hi[i] : s.lo[WIDE ? i - P : 0];
     __syncthreads();
+    s = first;
+    if (tid > 0) {
 #pragma unroll
-    for (int i = 0; i < P; ++i) s[i] = tid == 0 ? first[i] : sbuf[i * kSt + tid - 1];
+        for (int i = 0; i < P; ++i) {
+            s.hi[i] = sbuf[i * kSt + tid - 1];
+            if (WIDE) s.lo[i] = sbuf[(P + i) * kSt + tid - 1];
+        }
+    }
     for (unsigned k = k0; k < k1; ++k) {
-#pragma unroll
-        for (int i = 0; i < P; ++i) c[k * P + i] = s[i];
-        double nxt[P];
-#pragma unroll
-        for (int i = 0; i < P; ++i) nxt[i] = z[k * P + i];
-        mat_acc<P>(nxt, mats2, s);
-#pragma unroll
-        for (int i = 0; i < P; ++i) s[i] = nxt[i];
+        sv_store<P, WIDE>(s, c + static_cast<size_t>(k) * W);
+        SVec<P, WIDE> nxt;
+        sv_load<P, WIDE>(nxt, z + static_cast<size_t>(k) * W);
+        sv_mat_acc<P, WIDE>(nxt, mats2, s);
+        s = nxt;
     }
 }
 
-// ---- host side: companion-matrix powers in double ------------------------------------------------
-using Mat = std::vector<long double>;  // x87 extended: 11 more mantissa bits than the device carries
+// ---- host side: companion-matrix powers in double-double ------------------------------------------
+using Mat = std::vector<DD>;
 
 Mat mat_mul(const Mat &a, const Mat &b, int P) {
-    Mat c(static_cast<size_t>(P) * P, 0.0L);
+    Mat c(static_cast<size_t>(P) * P, DD{0.0, 0.0});
     for (int i = 0; i < P; ++i)
-        for (int k = 0; k < P; ++k) {
-            const long double aik = a[i * P + k];
-            for (int j = 0; j < P; ++j) c[i * P + j] += aik * b[k * P + j];
-        }
+        for (int k = 0; k < P; ++k)
+            for (int j = 0; j < P; ++j) c[i * P + j] = dd_add(c[i * P + j], dd_mul(a[i * P + k], b[k * P + j]));
     return c;
 }
 
 Mat mat_identity(int P) {
-    Mat m(static_cast<size_t>(P) * P, 0.0L);
-    for (int i = 0; i < P; ++i) m[i * P + i] = 1.0L;
+    Mat m(static_cast<size_t>(P) * P, DD{0.0, 0.0});
+    for (int i = 0; i < P; ++i) m[i * P + i].hi = 1.0;
     return m;
 }
 
@@ -468,17 +567,22 @@ Mat mat_pow(Mat base, unsigned long long e, int P) {
 }
 
 double mat_norm_inf(const Mat &m, int P) {
-    long double worst = 0.0L;
+    double worst = 0.0;
     for (int i = 0; i < P; ++i) {
-        long double row = 0.0L;
-        for (int j = 0; j < P; ++j) row += fabsl(m[i * P + j]);
+        double row = 0.0;
+        for (int j = 0; j < P; ++j) row += std::fabs(m[i * P + j].hi);
         if (!(row <= worst)) worst = row;  // also catches NaN
     }
-    return static_cast<double>(worst);
+    return worst;
 }
 
-void store_mat(std::vector<double> &table, size_t slot, const Mat &m, int P) {
-    for (int i = 0; i < P * P; ++i) table[slot * P * P + i] = static_cast<double>(m[i]);
+// slot layout: P*P hi values [then P*P lo values when wide]
+void store_mat(std::vector<double> &table, size_t slot, const Mat &m, int P, bool wide) {
+    const size_t ms = static_cast<size_t>(wide ? 2 : 1) * P * P;
+    for (int i = 0; i < P * P; ++i) {
+        table[slot * ms + i] = m[i].hi;
+        if (wide) table[slot * ms + P * P + i] = m[i].lo;
+    }
 }
 
 // sum_k |h_k| of the all-pole part 1 / (1 - sum b_i z^-i): how much one rounding error injected into
@@ -486,9 +590,8 @@ void store_mat(std::vector<double> &table, size_t slot, const Mat &m, int P) {
 double feedback_noise_gain(const IirCoef &co) {
     const int P = co.poles;
     double h[9] = {0};
-    double total = 0.0;
+    double total = 1.0;
     h[0] = 1.0;  // h[i] = response i steps ago
-    total = 1.0;
     for (int k = 1; k < (1 << 22); ++k) {
         double v = 0.0;
         for (int i = 1; i <= P; ++i) v += co.b[i] * h[i - 1];
@@ -505,50 +608,14 @@ double feedback_noise_gain(const IirCoef &co) {
     return total;
 }
 
-template <int P, bool ALIGNED>
-int scan_dispatch(const float *x, float *y, size_t channels, size_t n, const IirCoef &co, double *state,
-                  hipStream_t s) {
-    // companion matrix in the vh ordering: S = (v[t-1], ..., v[t-P])
-    Mat A(static_cast<size_t>(P) * P, 0.0L);
-    for (int i = 0; i < P; ++i) A[i] = co.b[i + 1];
-    for (int i = 1; i < P; ++i) A[i * P + i - 1] = 1.0L;
-    std::vector<double> table(static_cast<size_t>(9 + 9) * P * P, 0.0);
-    Mat m = mat_pow(A, kRow, P);
-    double amp = 0.0;  // largest carry matrix the scan multiplies a state with
-    int levels = kLevels + 1;  // doubling levels whose matrix still matters (norm > 2^-60)
-    for (int j = 0; j <= kLevels; ++j) {
-        store_mat(table, j, m, P);
-        const double nrm = mat_norm_inf(m, P);
-        amp = std::max(amp, nrm);
-        if (nrm <= 0x1p-60 && levels > j) levels = j;
-        if (j < kLevels) m = mat_mul(m, m, P);
-    }
-    const Mat MT = m;  // A^8192
-    // Conditioning guard.  A carry S += M S' rounds at ||M|| * 2^-53 relative to the state, and the
-    // recursion amplifies an injected error by the feedback noise gain; calibrated on the 4-pole
-    // Chebyshev at fc = 0.01 (predicted 5e-5, measured 5.4e-5).  Direct-form filters with poles
-    // clustered at the unit circle exceed the 1e-4 budget of the scan: those are refused here
-    // (DSP_GPU_IIR_AUTO then runs them sequentially in BATCH mode).
-    const double predicted = 64.0 * amp * feedback_noise_gain(co) * 0x1p-52;
-    if (!(predicted <= 1e-4))
-        return fail(DSP_GPU_EUNSUPPORTED,
-                    "IIR scan: filter too ill-conditioned for block-parallel carries in double "
-                    "(predicted relative error %.2e > 1e-4); use DSP_GPU_IIR_BATCH", predicted);
-
-    // warm-up horizon: smallest multiple of 32 with ||A^W||_inf <= 2^-44, if it is short enough
-    int warm = -1;
-    {
-        const Mat a32 = mat_pow(A, kRow, P);
-        Mat acc = a32;
-        for (int w = kRow; w <= kTile / 8; w += kRow) {
-            if (mat_norm_inf(acc, P) <= 0x1p-44) {
-                warm = w;
-                break;
-            }
-            acc = mat_mul(acc, a32, P);
-        }
-    }
-    if (channels > 65535) return fail(DSP_GPU_EUNSUPPORTED, "IIR scan: more than 65535 channels per call");
+template <int P, bool ALIGNED, bool WIDE>
+int scan_launch(const float *x, float *y, size_t channels, size_t n, const IirCoef &co, const double *state_in,
+                double *state, const std::vector<Mat> &pow32, const Mat &A, int levels, int warm, hipStream_t s) {
+    constexpr int W = kWords<P, WIDE>;
+    const size_t ms = static_cast<size_t>(W) * P;
+    std::vector<double> table(static_cast<size_t>(9 + 9) * ms, 0.0);
+    for (int j = 0; j <= kLevels; ++j) store_mat(table, j, pow32[j], P, WIDE);
+    const Mat &MT = pow32[kLevels];  // A^8192
     const bool fused = warm > 0 || n <= static_cast<size_t>(kTile);
     if (warm < 0) warm = 0;
     unsigned ntiles;
@@ -556,13 +623,134 @@ int scan_dispatch(const float *x, float *y, size_t channels, size_t n, const Iir
     else ntiles = static_cast<unsigned>((n + kTile - 1) / kTile);
     const unsigned G = (ntiles + kSt - 1) / kSt;
     if (!fused) {
-        store_mat(table, 9, MT, P);
+        store_mat(table, 9, MT, P, WIDE);
         Mat mg = mat_pow(MT, G, P);
         for (int j = 0; j < kLevels; ++j) {
-            store_mat(table, 10 + j, mg, P);
+            store_mat(table, 10 + j, mg, P, WIDE);
             mg = mat_mul(mg, mg, P);
         }
     }
+    (void)A;
+    void *d_table_v = nullptr;
+    if (int rc = workspace(WS_IIR_TABLE, table.size() * sizeof(double), &d_table_v)) return rc;
+    double *d_table = static_cast<double *>(d_table_v);
+    // pageable source: the runtime stages the bytes before returning, `table` may go out of scope
+    DSPGPU_HIP(hipMemcpyAsync(d_table, table.data(), table.size() * sizeof(double), hipMemcpyHostToDevice, s));
+
+    const dim3 grid(8u * ((ntiles + 7u) / 8u), static_cast<unsigned>(channels));
+    if (fused) {
+        hipLaunchKernelGGL((iir_scan_kernel<P, SCAN_FUSED, ALIGNED, WIDE>), grid, dim3(kSt), 0, s, x, y, n, co, d_table,
+                           state_in, state, nullptr, nullptr, ntiles, warm, levels);
+        return check_launch("iir_scan_kernel<fused>");
+    }
+    void *z_v = nullptr, *c_v = nullptr;
+    const size_t carry_bytes = channels * ntiles * W * sizeof(double);
+    if (int rc = workspace(WS_SCRATCH_A, carry_bytes, &z_v)) return rc;
+    if (int rc = workspace(WS_SCRATCH_B, carry_bytes, &c_v)) return rc;
+    double *tz = static_cast<double *>(z_v), *tc = static_cast<double *>(c_v);
+    hipLaunchKernelGGL((iir_scan_kernel<P, SCAN_REDUCE, ALIGNED, WIDE>), grid, dim3(kSt), 0, s, x, y, n, co, d_table,
+                       state_in, nullptr, tz, nullptr, ntiles, 0, levels);
+    if (int rc = check_launch("iir_scan_kernel<reduce>")) return rc;
+    hipLaunchKernelGGL((iir_carry_kernel<P, WIDE>), dim3(static_cast<unsigned>(channels)), dim3(kSt), 0, s, tz, tc,
+                       d_table + 9 * ms, state_in, ntiles, G);
+    if (int rc = check_launch("iir_carry_kernel")) return rc;
+    hipLaunchKernelGGL((iir_scan_kernel<P, SCAN_APPLY, ALIGNED, WIDE>), grid, dim3(kSt), 0, s, x, y, n, co, d_table,
+                       state_in, state, nullptr, tc, ntiles, 0, levels);
+    return check_launch("iir_scan_kernel<apply>");
+}
+
+// What the host works out once per coefficient set (cached): the companion powers and the decisions
+// that follow from them.
+struct ScanPlan {
+    IirCoef co;
+    std::vector<Mat> pow32;  // A^(32*2^j), j = 0..8
+    int levels = 0;          // doubling levels whose matrix still matters (norm > 2^-60)
+    int warm = -1;           // smallest multiple of 32 with ||A^W||_inf <= 2^-44 (<= kTile/8), else -1
+    bool wide = false;       // carry states in double-double
+    double predicted = 0.0;  // predicted relative error of the chosen carry arithmetic
+    bool usable = false;
+};
+
+// Powers of the companion matrix by RUNNING the recursion: column c of A^k is the feedback state after k
+// zero-input steps from the unit state e_c.  Done in double-double this is as well conditioned as the
+// filter itself, whereas repeated squaring of this highly non-normal matrix loses three digits per
+// squaring (measured at fc = 0.001: A^1024 only 3e-13 accurate even in double-double).
+void build_plan(const IirCoef &co, ScanPlan &plan) {
+    const int P = co.poles;
+    plan.co = co;
+    plan.pow32.assign(kLevels + 1, Mat(static_cast<size_t>(P) * P, DD{0.0, 0.0}));
+    std::vector<DD> st(static_cast<size_t>(P) * P);  // st[c*P + i] = state component i of the run started from e_c
+    for (int c = 0; c < P; ++c)
+        for (int i = 0; i < P; ++i) st[c * P + i] = DD{i == c ? 1.0 : 0.0, 0.0};
+    double amp = 0.0;
+    plan.levels = kLevels + 1;
+    plan.warm = -1;
+    int next_level = 0;
+    for (int k = 1; k <= kTile; ++k) {
+        for (int c = 0; c < P; ++c) {
+            DD v{0.0, 0.0};
+            for (int i = 0; i < P; ++i) v = dd_add(v, dd_mul(DD{co.b[i + 1], 0.0}, st[c * P + i]));
+            for (int i = P - 1; i >= 1; --i) st[c * P + i] = st[c * P + i - 1];
+            st[c * P] = v;
+        }
+        if (k % kRow) continue;
+        double nrm = 0.0;  // ||A^k||_inf: rows are state components, columns the start vectors
+        for (int i = 0; i < P; ++i) {
+            double row = 0.0;
+            for (int c = 0; c < P; ++c) row += std::fabs(st[c * P + i].hi);
+            if (!(row <= nrm)) nrm = row;
+        }
+        if (plan.warm < 0 && k <= kTile / 8 && nrm <= 0x1p-44) plan.warm = k;
+        if (k == (kRow << next_level)) {
+            Mat &m = plan.pow32[next_level];
+            for (int i = 0; i < P; ++i)
+                for (int c = 0; c < P; ++c) m[i * P + c] = st[c * P + i];
+            amp = std::max(amp, nrm);
+            if (!(nrm == nrm)) amp = 1e300;
+            if (nrm <= 0x1p-60 && plan.levels > next_level) plan.levels = next_level;
+            ++next_level;
+            if (nrm <= 0x1p-200) break;  // everything later is zero for all purposes (left as zeros)
+        }
+    }
+    // Conditioning.  A carry S += M S' in double rounds at ||M|| * 2^-53 relative to the state and the
+    // recursion amplifies an injected error by the feedback noise gain (calibrated on the 4-pole
+    // Chebyshev at fc = 0.01: predicted 5e-5, measured 5.4e-5 with double carries).  Direct-form
+    // sections with poles clustered at the unit circle therefore carry their states in double-double
+    // (matrices included); what even that cannot hold inside the 1e-4 budget -- unstable filters -- is
+    // refused (DSP_GPU_IIR_AUTO then runs the channel sequentially in BATCH mode).
+    const double gain = feedback_noise_gain(co);
+    const double predicted_double = 64.0 * amp * gain * 0x1p-52;
+    plan.wide = !(predicted_double <= 2e-7);
+    plan.predicted = plan.wide ? 64.0 * amp * gain * 0x1p-100 : predicted_double;
+    plan.usable = plan.predicted <= 1e-4 && amp < 1e200;
+}
+
+std::mutex g_plan_mutex;
+std::vector<ScanPlan> g_plans;  // small cache: a filter is usually applied many times
+
+const ScanPlan *cached_plan(const IirCoef &co, ScanPlan &local) {
+    std::lock_guard<std::mutex> lock(g_plan_mutex);
+    for (const ScanPlan &p : g_plans)
+        if (p.co.poles == co.poles && std::memcmp(p.co.a, co.a, sizeof co.a) == 0 && std::memcmp(p.co.b, co.b, sizeof co.b) == 0) {
+            local = p;  // copy out: the cache may be rotated by another thread
+            return &local;
+        }
+    build_plan(co, local);
+    if (g_plans.size() >= 16) g_plans.erase(g_plans.begin());
+    g_plans.push_back(local);
+    return &local;
+}
+
+template <int P, bool ALIGNED>
+int scan_dispatch(const float *x, float *y, size_t channels, size_t n, const IirCoef &co, double *state,
+                  hipStream_t s) {
+    if (channels > 65535) return fail(DSP_GPU_EUNSUPPORTED, "IIR scan: more than 65535 channels per call");
+    ScanPlan plan;
+    cached_plan(co, plan);
+    if (!plan.usable)
+        return fail(DSP_GPU_EUNSUPPORTED,
+                    "IIR scan: filter too ill-conditioned for block-parallel carries "
+                    "(predicted relative error %.2e > 1e-4); use DSP_GPU_IIR_BATCH", plan.predicted);
     // tile 0 reads the caller's history while the last tile writes the new one: read from a snapshot
     const double *state_in = state;
     if (state) {
@@ -572,32 +760,9 @@ int scan_dispatch(const float *x, float *y, size_t channels, size_t n, const Iir
         DSPGPU_HIP(hipMemcpyAsync(snap, state, sb, hipMemcpyDeviceToDevice, s));
         state_in = static_cast<const double *>(snap);
     }
-    void *d_table_v = nullptr;
-    if (int rc = workspace(WS_IIR_TABLE, table.size() * sizeof(double), &d_table_v)) return rc;
-    double *d_table = static_cast<double *>(d_table_v);
-    // pageable source: the runtime stages the bytes before returning, `table` may go out of scope
-    DSPGPU_HIP(hipMemcpyAsync(d_table, table.data(), table.size() * sizeof(double), hipMemcpyHostToDevice, s));
-
-    const dim3 grid(8u * ((ntiles + 7u) / 8u), static_cast<unsigned>(channels));
-    if (fused) {
-        hipLaunchKernelGGL((iir_scan_kernel<P, SCAN_FUSED, ALIGNED>), grid, dim3(kSt), 0, s, x, y, n, co, d_table,
-                           state_in, state, nullptr, nullptr, ntiles, warm, levels);
-        return check_launch("iir_scan_kernel<fused>");
-    }
-    void *z_v = nullptr, *c_v = nullptr;
-    const size_t carry_bytes = channels * ntiles * P * sizeof(double);
-    if (int rc = workspace(WS_SCRATCH_A, carry_bytes, &z_v)) return rc;
-    if (int rc = workspace(WS_SCRATCH_B, carry_bytes, &c_v)) return rc;
-    double *tz = static_cast<double *>(z_v), *tc = static_cast<double *>(c_v);
-    hipLaunchKernelGGL((iir_scan_kernel<P, SCAN_REDUCE, ALIGNED>), grid, dim3(kSt), 0, s, x, y, n, co, d_table,
-                       state_in, nullptr, tz, nullptr, ntiles, 0, levels);
-    if (int rc = check_launch("iir_scan_kernel<reduce>")) return rc;
-    hipLaunchKernelGGL((iir_carry_kernel<P>), dim3(static_cast<unsigned>(channels)), dim3(kSt), 0, s, tz, tc,
-                       d_table + static_cast<size_t>(9) * P * P, state_in, ntiles, G);
-    if (int rc = check_launch("iir_carry_kernel")) return rc;
-    hipLaunchKernelGGL((iir_scan_kernel<P, SCAN_APPLY, ALIGNED>), grid, dim3(kSt), 0, s, x, y, n, co, d_table,
-                       state_in, state, nullptr, tc, ntiles, 0, levels);
-    return check_launch("iir_scan_kernel<apply>");
+    const Mat unused;
+    return plan.wide ? scan_launch<P, ALIGNED, true>(x, y, channels, n, co, state_in, state, plan.pow32, unused, plan.levels, plan.warm, s)
+                     : scan_launch<P, ALIGNED, false>(x, y, channels, n, co, state_in, state, plan.pow32, unused, plan.levels, plan.warm, s);
 }
 
 template <int P, bool ALIGNED>
