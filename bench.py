@@ -37,7 +37,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="fft",
-                    choices=["fft", "fir_direct", "fir_os", "iir_batch", "iir_scan", "mavg"])
+                    choices=["fft", "fir_direct", "fir_os", "iir_batch", "iir_scan", "mavg", "fft_dist"])
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: every GPU gets the full per-GPU batch; strong: the one-GPU batch is channel-sharded")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -134,6 +134,26 @@ def make_iir(torch, dev, ops, rank, mode):
     return step, channels * n, meta
 
 
+def make_fft_dist(torch, dev, world, rank):
+    """C5: ONE transform of world * 2^27 points (2^30 on 8 GPUs), six-step with all-to-all over xGMI."""
+    from dsp_amd import dist_fft
+    log2n = 27 + (world.bit_length() - 1)
+    per_rank = (1 << log2n) // world
+    g = torch.Generator(device=dev).manual_seed(2030 + rank)
+    x = 0.01 * torch.view_as_complex(torch.randn(per_rank, 2, device=dev, generator=g))
+    local_ops = dist_fft.GpuLocalOps()
+
+    def step():
+        dist_fft.fft_dist(x, log2n, False, ops=local_ops)
+
+    meta = dict(metric="distributed_fft_throughput", unit="GSamples/s", dtype="f32", bound="hbm",
+                alg_per_unit=48.0, alg_unit="bytes/sample (3 local passes x 16 B; the exchanges ride xGMI)",
+                kernel="fft_column_kernel + fft_lds_kernel + swap_axes_kernel + transpose_blocks_kernel",
+                config={"workload": f"C5: one 2^{log2n}-point complex fp32 FFT, six-step, {world} GPU(s), 2^27 points per GPU",
+                        "log2n": log2n, "exchange": "3 x all_to_all_single (RCCL)"})
+    return step, per_rank, meta
+
+
 def sinc_taps_host(cf, length):
     """dsp::sinc (dsp.h:47-79), Blackman window: host-side design in double."""
     from dsp_amd import design
@@ -163,6 +183,12 @@ def cpu_baseline(workload, seconds):
             lib.fft0(x)
             units += chunk * 4096
         unit, sample = "GSamples/s", f"{units // 4096} of 65,536 transforms, fft0 in complex double as the reference computes (fft.h:31-55)"
+    elif workload == "fft_dist":
+        x = (rng.standard_normal(1 << 20) + 1j * rng.standard_normal(1 << 20))
+        while time.perf_counter() < t_end:
+            lib.fft0(x)
+            units += x.size
+        unit, sample = "GSamples/s", "fft0 of 2^20 points in complex double (fft.h:31-55), repeated; 2^27+ does not fit a bounded CPU sample"
     elif workload in ("fir_direct", "fir_os"):
         h = sinc_taps_host(0.1, 511)
         x = rng.standard_normal(1 << 16).astype(np.float32)
@@ -214,7 +240,9 @@ def main():
     global SHARD
     if args.scaling == "strong":
         SHARD = (rank, world)
-    if args.workload == "fft":
+    if args.workload == "fft_dist":
+        step, units, meta = make_fft_dist(torch, dev, world, rank)
+    elif args.workload == "fft":
         step, units, meta = make_fft(torch, dev, ops, rank)
     elif args.workload in ("fir_direct", "fir_os"):
         step, units, meta = make_fir(torch, dev, ops, rank, "direct" if args.workload == "fir_direct" else "overlap_save")
