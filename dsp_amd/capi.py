@@ -23,6 +23,7 @@ EXPORTS = (
     "dsp_gpu_fft_batch",
     "dsp_gpu_fft_real_batch",
     "dsp_gpu_convolve",
+    "dsp_gpu_convolve_stream",
     "dsp_gpu_moving_average",
     "dsp_gpu_iir",
     "dsp_gpu_device_count",
@@ -57,6 +58,8 @@ def lib() -> C.CDLL:
         L.dsp_gpu_fft_batch_timed.argtypes = [vp, vp, i, sz, i, i, C.POINTER(C.c_float), vp]
         L.dsp_gpu_fft_real_batch.argtypes = [vp, sz, sz, vp, i, sz, i, i, i, vp]
         L.dsp_gpu_convolve.argtypes = [vp, vp, sz, sz, vp, i, i, i, vp]
+        L.dsp_gpu_convolve_stream.argtypes = [vp, vp, sz, sz, vp, i, vp, C.c_ulonglong, i, i, vp]
+        L.dsp_gpu_convolve_stream.restype = i
         L.dsp_gpu_moving_average.argtypes = [vp, vp, sz, sz, i, i, vp]
         L.dsp_gpu_iir.argtypes = [vp, vp, sz, sz, vp, vp, i, C.c_double, C.c_double, vp, i, i, vp]
         L.dsp_gpu_fft_columns.argtypes = [vp, vp, i, sz, i, vp]

@@ -237,15 +237,16 @@ int dsp_gpu_fft_real_batch(const float *in, size_t n_in, size_t in_stride, void 
     return stage_out(out, out_bytes, s, hs);
 }
 
-int dsp_gpu_convolve(const float *x, float *y, size_t channels, size_t n, const float *taps, int ntaps, int mode,
-                     int mem, void *stream) {
-    if (!x || !y || !taps) return fail(DSP_GPU_EINVAL, "dsp_gpu_convolve: null buffer");
-    if (ntaps < 1 || ntaps > 4096) return fail(DSP_GPU_EINVAL, "dsp_gpu_convolve: ntaps %d outside [1,4096]", ntaps);
+// shared by the one-shot and the streaming form; `history` == nullptr: one-shot (filter.h:123-140)
+static int convolve_impl(const char *who, const float *x, float *y, size_t channels, size_t n, const float *taps,
+                         int ntaps, float *history, unsigned long long position, int mode, int mem, void *stream) {
+    if (!x || !y || !taps) return fail(DSP_GPU_EINVAL, "%s: null buffer", who);
+    if (ntaps < 1 || ntaps > 4096) return fail(DSP_GPU_EINVAL, "%s: ntaps %d outside [1,4096]", who, ntaps);
     if (mode != DSP_GPU_CONV_AUTO && mode != DSP_GPU_CONV_DIRECT && mode != DSP_GPU_CONV_OVERLAP_SAVE)
-        return fail(DSP_GPU_EINVAL, "dsp_gpu_convolve: mode %d", mode);
+        return fail(DSP_GPU_EINVAL, "%s: mode %d", who, mode);
     if (mode == DSP_GPU_CONV_OVERLAP_SAVE && ntaps > 2049)
-        return fail(DSP_GPU_EINVAL, "dsp_gpu_convolve: overlap-save supports at most 2049 taps, got %d", ntaps);
-    if (bad_mem(mem)) return fail(DSP_GPU_EINVAL, "dsp_gpu_convolve: mem %d", mem);
+        return fail(DSP_GPU_EINVAL, "%s: overlap-save supports at most 2049 taps, got %d", who, ntaps);
+    if (bad_mem(mem)) return fail(DSP_GPU_EINVAL, "%s: mem %d", who, mem);
     if (channels == 0 || n == 0) return DSP_GPU_OK;
     if (mode == DSP_GPU_CONV_AUTO)  // long filters on long signals amortise the FFT blocks
         mode = (ntaps >= 64 && ntaps <= 2049 && n >= 4096) ? DSP_GPU_CONV_OVERLAP_SAVE : DSP_GPU_CONV_DIRECT;
@@ -253,18 +254,51 @@ int dsp_gpu_convolve(const float *x, float *y, size_t channels, size_t n, const 
     TapEntry *te = nullptr;
     if (int rc = cached_taps(taps, ntaps, mode == DSP_GPU_CONV_OVERLAP_SAVE, s, &te)) return rc;
     const size_t bytes = channels * n * sizeof(float);
+    const size_t hist_bytes = channels * static_cast<size_t>(ntaps - 1) * sizeof(float);
     const float *dx = x;
     float *dy = y;
+    float *dhist = history;
     HostStage hs;
     if (mem == DSP_GPU_MEM_HOST) {
         if (int rc = stage_in(x, bytes, bytes, s, &hs)) return rc;
         dx = static_cast<const float *>(hs.d_in);
         dy = static_cast<float *>(hs.d_out);
+        if (history && hist_bytes) {
+            void *p = nullptr;
+            if (int rc = workspace(WS_STATE, hist_bytes, &p)) return rc;
+            dhist = static_cast<float *>(p);
+            DSPGPU_HIP(hipMemcpyAsync(dhist, history, hist_bytes, hipMemcpyHostToDevice, s));
+        }
     }
-    int rc = mode == DSP_GPU_CONV_OVERLAP_SAVE ? launch_fir_overlap_save(dx, dy, channels, n, te->d_spectrum, ntaps, s)
-                                               : launch_fir_direct(dx, dy, channels, n, te->d_taps, ntaps, s);
+    // the kernels read the old history only when this is not the first chunk of a stream; outputs whose
+    // stream index is below ntaps-1 stay zero wherever the chunk boundaries fall (filter.h:126,133)
+    const float *old_hist = (history && position && hist_bytes) ? dhist : nullptr;
+    const unsigned long long order = static_cast<unsigned long long>(ntaps - 1);
+    const int zero_head = position >= order ? 0 : static_cast<int>(order - position);
+    int rc = mode == DSP_GPU_CONV_OVERLAP_SAVE
+                 ? launch_fir_overlap_save(dx, dy, channels, n, te->d_spectrum, ntaps, old_hist, zero_head, s)
+                 : launch_fir_direct(dx, dy, channels, n, te->d_taps, ntaps, old_hist, zero_head, s);
     if (rc) return rc;
+    if (history && hist_bytes) {  // new history = last ntaps-1 samples of (old history ++ x), via a scratch copy
+        void *p = nullptr;
+        if (int rc2 = workspace(WS_FIR_HIST, hist_bytes, &p)) return rc2;
+        if (int rc2 = launch_fir_history(dx, n, old_hist, static_cast<float *>(p), channels, ntaps, s)) return rc2;
+        DSPGPU_HIP(hipMemcpyAsync(dhist, p, hist_bytes, hipMemcpyDeviceToDevice, s));
+        if (mem == DSP_GPU_MEM_HOST) DSPGPU_HIP(hipMemcpyAsync(history, dhist, hist_bytes, hipMemcpyDeviceToHost, s));
+    }
     return mem == DSP_GPU_MEM_HOST ? stage_out(y, bytes, s, hs) : DSP_GPU_OK;
+}
+
+int dsp_gpu_convolve(const float *x, float *y, size_t channels, size_t n, const float *taps, int ntaps, int mode,
+                     int mem, void *stream) {
+    return convolve_impl("dsp_gpu_convolve", x, y, channels, n, taps, ntaps, nullptr, 0, mode, mem, stream);
+}
+
+int dsp_gpu_convolve_stream(const float *x, float *y, size_t channels, size_t n, const float *taps, int ntaps,
+                            float *history, unsigned long long position, int mode, int mem, void *stream) {
+    if (!history && ntaps > 1) return fail(DSP_GPU_EINVAL, "dsp_gpu_convolve_stream: null history");
+    return convolve_impl("dsp_gpu_convolve_stream", x, y, channels, n, taps, ntaps, history, position, mode, mem,
+                         stream);
 }
 
 int dsp_gpu_moving_average(const float *x, float *y, size_t channels, size_t n, int npoints, int mem, void *stream) {

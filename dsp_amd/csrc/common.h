@@ -57,7 +57,7 @@ __device__ __forceinline__ size_t xcd_tile_of(unsigned block, size_t chunk) {
 // Device workspace owned by the library (one growing buffer per device and slot).
 // Slots keep independent users (host staging in/out, FFT scratch, ...) from aliasing.
 enum WorkspaceSlot {
-    WS_STAGE_IN = 0, WS_STAGE_OUT, WS_SCRATCH_A, WS_SCRATCH_B, WS_STATE, WS_STATE_SNAP, WS_IIR_TABLE, WS_SLOTS
+    WS_STAGE_IN = 0, WS_STAGE_OUT, WS_SCRATCH_A, WS_SCRATCH_B, WS_STATE, WS_STATE_SNAP, WS_IIR_TABLE, WS_FIR_HIST, WS_SLOTS
 };
 int workspace(WorkspaceSlot slot, size_t bytes, void **ptr);
 void release_all_workspaces();
@@ -71,9 +71,11 @@ int launch_swap_axes(const float2 *in, float2 *out, size_t a, size_t b, size_t c
                      unsigned long long row0, int direction, hipStream_t s);
 int launch_transpose_blocks(const float2 *in, float2 *out, size_t blocks, size_t rows, size_t cols, hipStream_t s);
 int launch_fir_direct(const float *x, float *y, size_t channels, size_t n, const float *d_taps,
-                      int ntaps, hipStream_t s);
+                      int ntaps, const float *hist, int zero_head, hipStream_t s);
+int launch_fir_history(const float *x, size_t n, const float *old_hist, float *new_hist, size_t channels,
+                       int ntaps, hipStream_t s);
 int launch_fir_overlap_save(const float *x, float *y, size_t channels, size_t n, const float2 *d_hspec,
-                            int ntaps, hipStream_t s);
+                            int ntaps, const float *hist, int zero_head, hipStream_t s);
 int launch_fir_spectrum(const float *d_taps, int ntaps, float2 *d_hspec, hipStream_t s);
 int launch_moving_average(const float *x, float *y, size_t channels, size_t n, int npoints, hipStream_t s);
 

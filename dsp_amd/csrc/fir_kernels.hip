@@ -45,7 +45,7 @@ constexpr int kFirOutPerWg = kFirWaves * kFirAcc * kFirTile * kFirPasses;  // 81
 template <bool ALIGNED>
 __global__ __launch_bounds__(kFirThreads) void fir_direct_kernel(const float *__restrict__ x, float *__restrict__ y,
                                                                   size_t n, const float *__restrict__ taps, int ntaps,
-                                                                  int Q) {
+                                                                  int Q, const float *__restrict__ prev, int zero_head) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int hist = 16 * (Q - 1);
     const int xs_len = hist + kFirOutPerWg;
@@ -59,6 +59,9 @@ __global__ __launch_bounds__(kFirThreads) void fir_direct_kernel(const float *__
     const float *xc = x + ch * n;
     float *yc = y + ch * n;
     const long long nn = static_cast<long long>(n);
+    // streaming form: prev[ch][ntaps-1] holds the samples before x[0] (oldest first) and every output is kept
+    const long long hlen = ntaps - 1;
+    const float *hc = prev ? prev + ch * hlen : nullptr;
 
     // taps: 4 shifted reversed copies
     for (int i = tid; i < 4 * taps_len; i += kFirThreads) {
@@ -74,10 +77,13 @@ __global__ __launch_bounds__(kFirThreads) void fir_direct_kernel(const float *__
         if (ALIGNED && g >= 0 && g + 3 < nn) {
             v = *reinterpret_cast<const float4 *>(xc + g);
         } else {
-            v.x = (g >= 0 && g < nn) ? xc[g] : 0.0f;
-            v.y = (g + 1 >= 0 && g + 1 < nn) ? xc[g + 1] : 0.0f;
-            v.z = (g + 2 >= 0 && g + 2 < nn) ? xc[g + 2] : 0.0f;
-            v.w = (g + 3 >= 0 && g + 3 < nn) ? xc[g + 3] : 0.0f;
+            float e[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const long long gi = g + q;
+                e[q] = (gi >= 0 && gi < nn) ? xc[gi] : ((hc && gi < 0 && gi >= -hlen) ? hc[hlen + gi] : 0.0f);
+            }
+            v = make_float4(e[0], e[1], e[2], e[3]);
         }
         *reinterpret_cast<float4 *>(xs + u) = v;
     }
@@ -87,7 +93,7 @@ __global__ __launch_bounds__(kFirThreads) void fir_direct_kernel(const float *__
     const int r = lane & 15, kq = lane >> 4;  // r: A row / B column, kq: k slot
     const int s = (4 - (r & 3)) & 3;
     const float *a_ptr = as + s * taps_len + (16 * Q - s - r + 4 * kq);  // minus 16 q per step
-    const int order = ntaps - 1;
+    const int order = zero_head;  // outputs before the stream's first full window stay zero (filter.h:133)
 
 #pragma unroll 1
     for (int pass = 0; pass < kFirPasses; ++pass) {
@@ -150,7 +156,8 @@ constexpr int kOsLog2N = 12;
 // outputs [order + b*L, order + (b+1)*L) from inputs [b*L, b*L + 4096), L = 4096 - order.
 __global__ __launch_bounds__(kThreads) void fir_overlap_save_kernel(const float *__restrict__ x, float *__restrict__ y,
                                                                     size_t n, const c32 *__restrict__ hspec, int ntaps,
-                                                                    unsigned pairs_per_channel, size_t tiles, size_t chunk) {
+                                                                    unsigned pairs_per_channel, size_t tiles, size_t chunk,
+                                                                    const float *__restrict__ hist, int zero_head) {
     __shared__ c32 lds[kLdsElems];
     const int tid = threadIdx.x;
     const size_t tile = xcd_tile_of(blockIdx.x, chunk);  // each XCD streams a contiguous range of block pairs
@@ -159,16 +166,22 @@ __global__ __launch_bounds__(kThreads) void fir_overlap_save_kernel(const float 
     const unsigned pair = static_cast<unsigned>(tile % pairs_per_channel);
     const long long order = ntaps - 1;
     const long long L = kOsN - order;
-    const long long nn = static_cast<long long>(n);
-    const float *xc = x + ch * n;
-    float *yc = y + ch * n;
+    // streaming form: the blocks run over the virtual signal history ++ x (hoff = ntaps-1 samples of
+    // history in front), so every output of x is kept; one-shot form: hoff = 0 and y[0, order) = 0
+    const long long hoff = hist ? order : 0;
+    const long long nn = static_cast<long long>(n) + hoff;
+    const float *xc = x + ch * n - hoff;       // xc[v] valid for v >= hoff
+    float *yc = y + ch * n - hoff;
+    const float *hc = hist ? hist + ch * order : nullptr;
     const long long in_a = static_cast<long long>(2 * pair) * L, in_b = in_a + L;
 
     c32 r[kPoints];
 #pragma unroll
     for (int m = 0; m < kPoints; ++m) {
         const long long ia = in_a + tid + kThreads * m, ib = in_b + tid + kThreads * m;
-        r[m] = make_float2(ia < nn ? __builtin_nontemporal_load(xc + ia) : 0.0f, ib < nn ? __builtin_nontemporal_load(xc + ib) : 0.0f);
+        const float va = ia >= nn ? 0.0f : (ia >= hoff ? __builtin_nontemporal_load(xc + ia) : hc[ia]);
+        const float vb = ib >= nn ? 0.0f : (ib >= hoff ? __builtin_nontemporal_load(xc + ib) : hc[ib]);
+        r[m] = make_float2(va, vb);
     }
     fft_passes<kOsLog2N, +1>(r, lds, tid, 0);
     constexpr float scale = 1.0f / kOsN;
@@ -181,15 +194,16 @@ __global__ __launch_bounds__(kThreads) void fir_overlap_save_kernel(const float 
     __syncthreads();  // the forward passes' last LDS image has been read by everyone
     fft_passes<kOsLog2N, -1>(r, lds, tid, 0);
 
-    if (pair == 0)  // filter.h:126,133: the first `order` outputs of the channel stay zero
+    if (pair == 0 && !hist)  // filter.h:126,133: the first `order` outputs of the channel stay zero
         for (long long j = tid; j < order && j < nn; j += kThreads) yc[j] = 0.0f;
 #pragma unroll
     for (int m = 0; m < kPoints; ++m) {
         const long long k = tid + kThreads * m;
         if (k < order) continue;  // wrapped (circular) part of the block
         const long long ja = in_a + k, jb = in_b + k;
-        if (ja < nn) __builtin_nontemporal_store(r[m].x, yc + ja);
-        if (jb < nn) __builtin_nontemporal_store(r[m].y, yc + jb);
+        // streaming: outputs before the stream's first full window stay zero like the one-shot head
+        if (ja < nn) __builtin_nontemporal_store(ja - hoff < zero_head ? 0.0f : r[m].x, yc + ja);
+        if (jb < nn) __builtin_nontemporal_store(jb - hoff < zero_head ? 0.0f : r[m].y, yc + jb);
     }
 }
 
@@ -318,10 +332,32 @@ __global__ __launch_bounds__(kThreads) void moving_average_kernel(const float *_
     }
 }
 
+// new_hist[ch][k] = virtual[n + k], k < hlen, where virtual = old_hist ++ x (old_hist == nullptr: zeros)
+__global__ __launch_bounds__(kThreads) void fir_history_kernel(const float *__restrict__ x, size_t n,
+                                                               const float *__restrict__ old_hist,
+                                                               float *__restrict__ new_hist, size_t channels, size_t hlen) {
+    const size_t total = channels * hlen;
+    for (size_t i = static_cast<size_t>(blockIdx.x) * kThreads + threadIdx.x; i < total;
+         i += static_cast<size_t>(gridDim.x) * kThreads) {
+        const size_t ch = i / hlen, k = i % hlen;
+        const size_t v = n + k;  // index into old_hist ++ x
+        new_hist[i] = v >= hlen ? x[ch * n + (v - hlen)] : (old_hist ? old_hist[ch * hlen + v] : 0.0f);
+    }
+}
+
 }  // namespace
 
+int launch_fir_history(const float *x, size_t n, const float *old_hist, float *new_hist, size_t channels, int ntaps,
+                       hipStream_t s) {
+    const size_t hlen = static_cast<size_t>(ntaps - 1);
+    if (hlen == 0 || channels == 0) return DSP_GPU_OK;
+    const unsigned grid = static_cast<unsigned>(std::min<size_t>((channels * hlen + kThreads - 1) / kThreads, 65536));
+    hipLaunchKernelGGL(fir_history_kernel, dim3(grid), dim3(kThreads), 0, s, x, n, old_hist, new_hist, channels, hlen);
+    return check_launch("fir_history_kernel");
+}
+
 int launch_fir_direct(const float *x, float *y, size_t channels, size_t n, const float *d_taps, int ntaps,
-                      hipStream_t s) {
+                      const float *hist, int zero_head, hipStream_t s) {
     const int order = ntaps - 1;
     const int Q = (order + 15) / 16 + 1;
     const size_t lds_bytes = (static_cast<size_t>(16 * (Q - 1) + kFirOutPerWg) + 4u * (16 * Q + 16)) * sizeof(float);
@@ -332,7 +368,7 @@ int launch_fir_direct(const float *x, float *y, size_t channels, size_t n, const
     if (lds_bytes > 64 * 1024)
         DSPGPU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        static_cast<int>(lds_bytes)));
-    hipLaunchKernelGGL(kern, dim3(blocks, channels), dim3(kFirThreads), lds_bytes, s, x, y, n, d_taps, ntaps, Q);
+    hipLaunchKernelGGL(kern, dim3(blocks, channels), dim3(kFirThreads), lds_bytes, s, x, y, n, d_taps, ntaps, Q, hist, zero_head);
     return check_launch("fir_direct_kernel");
 }
 
@@ -343,10 +379,11 @@ int launch_fir_spectrum(const float *d_taps, int ntaps, float2 *d_hspec, hipStre
 }
 
 int launch_fir_overlap_save(const float *x, float *y, size_t channels, size_t n, const float2 *d_hspec, int ntaps,
-                            hipStream_t s) {
+                            const float *hist, int zero_head, hipStream_t s) {
     const long long order = ntaps - 1;
     const long long L = kOsN - order;
-    const long long valid = static_cast<long long>(n) > order ? static_cast<long long>(n) - order : 0;
+    const long long nv = static_cast<long long>(n) + (hist ? order : 0);  // length of the (virtual) signal
+    const long long valid = nv > order ? nv - order : 0;
     long long nblocks = (valid + L - 1) / L;
     if (nblocks < 1) nblocks = 1;  // block 0 also zero-fills y[0, order)
     const unsigned pairs = static_cast<unsigned>((nblocks + 1) / 2);
@@ -354,7 +391,7 @@ int launch_fir_overlap_save(const float *x, float *y, size_t channels, size_t n,
     const size_t chunk = (tiles + 7) / 8;
     if (8 * chunk > 0x7fffffffull) return fail(DSP_GPU_EUNSUPPORTED, "overlap-save FIR: grid too large");
     hipLaunchKernelGGL(fir_overlap_save_kernel, dim3(static_cast<unsigned>(8 * chunk)), dim3(kThreads), 0, s, x, y, n,
-                       d_hspec, ntaps, pairs, tiles, chunk);
+                       d_hspec, ntaps, pairs, tiles, chunk, hist, zero_head);
     return check_launch("fir_overlap_save_kernel");
 }
 

@@ -103,6 +103,28 @@ def convolve(x, taps, mode: str = "auto", out=None):
     return y
 
 
+def convolve_stream(x, taps, history, position: int, mode: str = "direct", out=None):
+    """One chunk of a streamed FIR.  history: [channels, len(taps)-1] fp32 where x lives, updated in place;
+    position = samples of the stream consumed so far (0 starts it; the first len(taps)-1 outputs of the
+    stream are zero as in the one-shot call)."""
+    x, px, mem = _prep(x, np.float32, "float32")
+    taps = np.ascontiguousarray(taps, dtype=np.float32)
+    n = x.shape[-1]
+    channels = int(np.prod(x.shape[:-1])) if x.ndim > 1 else 1
+    if _is_torch(history) != _is_torch(x):
+        raise capi.DspGpuError(capi.EINVAL, "history must live where x lives")
+    want = channels * (taps.size - 1)
+    ok = (history.is_contiguous() and history.dtype == torch.float32 and history.numel() == want) if _is_torch(history) \
+        else (history.flags.c_contiguous and history.dtype == np.float32 and history.size == want)
+    if not ok:
+        raise capi.DspGpuError(capi.EINVAL, "history must be contiguous fp32 [channels, ntaps-1]")
+    y = out if out is not None else _empty_like(x, tuple(x.shape), np.float32, "float32")
+    capi.check(capi.lib().dsp_gpu_convolve_stream(px, _ptr(y), channels, n, taps.ctypes.data, taps.size,
+                                                  _ptr(history) if want else None, int(position), _MODES[mode], mem,
+                                                  _stream_of(x)))
+    return y
+
+
 def moving_average(x, npoints: int, out=None):
     """Centred moving average, zero edges.  filter.h:81-101."""
     x, px, mem = _prep(x, np.float32, "float32")

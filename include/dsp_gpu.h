@@ -91,6 +91,21 @@ int dsp_gpu_convolve(const float *x, float *y, size_t channels, size_t n, const 
                      int ntaps, int mode, int mem, void *stream);
 
 /*
+ * Streaming FIR: the same filter fed in chunks with the input tail carried between calls (the FIR
+ * counterpart of dsp_gpu_iir's `state`; the reference's block-wise callers are the audio callbacks of
+ * eval/recursive_filters/main.cpp:174-206).  `history` is [ch][ntaps-1] floats, the samples that precede
+ * x[0] (oldest first), read before and rewritten after the call; it lives where `mem` says.
+ * `position` = samples of this stream consumed by earlier calls (the caller adds n after each call).
+ * position == 0 starts a stream: `history` is ignored on input (taken as zeros).  Outputs whose stream
+ * index position + j is below ntaps-1 are zero exactly as in the one-shot call (filter.h:126,133), all
+ * others are   y[ch][j] = sum_i taps[i] * (history ++ x)[ntaps-1 + j - i].
+ * Feeding a signal in chunks of any sizes therefore reproduces dsp_gpu_convolve on the whole signal.
+ */
+int dsp_gpu_convolve_stream(const float *x, float *y, size_t channels, size_t n, const float *taps,
+                            int ntaps, float *history, unsigned long long position, int mode, int mem,
+                            void *stream);
+
+/*
  * Centred moving average.  Replaces dsp::filter::MovingAverageFilter::apply
  * (filter.h:81-101): with mid = npoints/2,
  *     y[i] = (sum_{k=i-mid}^{i+mid} x[k] - (npoints even ? x[npoints] : 0)) / npoints

@@ -261,6 +261,22 @@ struct SincFilter {
     }
     std::vector<double> kernel() const { return m_kernel; }
 
+    // Block-wise use (audio callbacks): feed consecutive blocks, the filter object carries the input tail.
+    // The concatenated outputs equal apply() on the concatenated input.  reset() starts a new stream.
+    template <typename Buffer>
+    Buffer stream(const Buffer &block, int mode = DSP_GPU_CONV_DIRECT) {
+        Buffer y(block.size());
+        if (block.size() == 0 || m_taps.empty()) return y;
+        m_history.resize(m_taps.size() - 1);
+        check(dsp_gpu_convolve_stream(detail::cptr(block), detail::mptr(y), 1, block.size(), m_taps.data(),
+                                      static_cast<int>(m_taps.size()), m_history.empty() ? nullptr : m_history.data(),
+                                      m_position, mode, DSP_GPU_MEM_HOST, nullptr),
+              "SincFilter::stream");
+        m_position += block.size();
+        return y;
+    }
+    void reset() { m_position = 0; }
+
   private:
     void design() {
         m_kernel = sinc<inversionType>(m_cutoffFrequency, static_cast<int>(m_length));
@@ -269,6 +285,8 @@ struct SincFilter {
     double m_cutoffFrequency{0};
     std::vector<double> m_kernel{};
     std::vector<float> m_taps{};
+    std::vector<float> m_history{};
+    unsigned long long m_position{0};
     size_t m_length{0};
 };
 

@@ -7,6 +7,7 @@
 #define DSP_MI355X_AS_DSP
 #include <dsp_mi355x/dsp.hpp>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -100,6 +101,15 @@ int run(const std::string &dir) {
         auto yf = convolve<Domain::Frequency>(one, kern);
         dump(dir + "/conv_time.f32", yt.data(), yt.size());
         dump(dir + "/conv_freq.f32", yf.data(), yf.size());
+        // block-wise streaming through the filter object (256-frame blocks like the reference's audio callback)
+        std::vector<float> streamed;
+        for (size_t pos = 0; pos < one.size(); pos += 256) {
+            const size_t len = std::min<size_t>(256, one.size() - pos);
+            SampleBuffer<float> blk(x.begin() + pos, x.begin() + pos + len);
+            auto yb = f.stream(blk);
+            streamed.insert(streamed.end(), yb.begin(), yb.end());
+        }
+        dump(dir + "/fir_streamed.f32", streamed.data(), streamed.size());
         filter::MovingAverageFilter ma(511);
         auto ym = ma(one);
         dump(dir + "/mavg.f32", ym.data(), ym.size());

@@ -70,6 +70,7 @@ def test_veneer_on_gpu(tmp_path, orc, golden, dev):
     want = orc.fir(fir_in.astype(np.float64), h)
     assert rel_l2(rd("fir_direct.f32", np.float32).reshape(2, 6000), want) <= 1e-6
     assert rel_l2(rd("conv_time.f32", np.float32), want[0]) <= 1e-6
+    assert rel_l2(rd("fir_streamed.f32", np.float32), want[0]) <= 1e-6  # 256-sample blocks, tail carried by the object
     assert rel_l2(rd("conv_freq.f32", np.float32), want[0]) <= 1.2e-4
     assert rel_l2(rd("mavg.f32", np.float32), orc.moving_average(fir_in[0].astype(np.float64), 511)) <= 1e-6
     assert rel_l2(rd("mavg8.f32", np.float32), orc.moving_average(fir_in[0].astype(np.float64), 8)) <= 1e-6

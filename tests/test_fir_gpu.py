@@ -179,3 +179,37 @@ def test_errors(ops, dev):
         ops.convolve(x, np.zeros(5000), "direct")
     with pytest.raises(capi.DspGpuError):
         ops.moving_average(x, 101)
+
+
+# ---- streaming FIR (carried input tail) ---------------------------------------------------------------
+@pytest.mark.parametrize("mode,tol", [("direct", DIRECT_TOL), ("overlap_save", OS_TOL)])
+@pytest.mark.parametrize("ntaps,chunks", [(511, [4096, 4096, 4096]), (511, [100, 7000, 3, 511, 510, 5000]),
+                                          (33, [1, 1, 30, 2000]), (2049, [3000, 50, 9000]), (1, [10, 20])])
+def test_streaming_equals_one_shot(ops, dev, orc, mode, tol, ntaps, chunks):
+    """Chunks of any size with the input tail carried == the one-shot call on the whole signal
+    (the FIR counterpart of the IIR state; block-wise callers: eval/recursive_filters/main.cpp:174-206)."""
+    import torch
+    rng = np.random.default_rng(ntaps + len(chunks))
+    h = orc.sinc(0.2, ntaps)[:ntaps] if ntaps > 1 else np.array([0.75])
+    n = sum(chunks)
+    x = rng.standard_normal((3, n)).astype(np.float32)
+    want = orc.fir(x.astype(np.float64), h)
+    xd = torch.from_numpy(x).to(dev)
+    hist = torch.full((3, ntaps - 1), 123.0, device=dev)  # garbage: must be ignored on the first chunk
+    outs, pos = [], 0
+    for i, c in enumerate(chunks):
+        outs.append(ops.convolve_stream(xd[:, pos:pos + c].contiguous(), h, hist, pos, mode=mode))
+        pos += c
+    got = torch.cat(outs, dim=1).cpu().numpy()
+    assert rel_l2(got, want) <= tol
+    assert not got[:, : min(n, ntaps - 1)].any()
+    if ntaps > 1:  # the carried tail is the last ntaps-1 input samples
+        tail = np.concatenate([np.zeros((3, max(0, ntaps - 1 - n)), np.float32), x[:, max(0, n - (ntaps - 1)):]], axis=1)
+        assert np.array_equal(hist.cpu().numpy(), tail)
+    # host-pointer path
+    hh = np.zeros((3, ntaps - 1), dtype=np.float32)
+    outs, pos = [], 0
+    for i, c in enumerate(chunks):
+        outs.append(ops.convolve_stream(np.ascontiguousarray(x[:, pos:pos + c]), h, hh, pos, mode=mode))
+        pos += c
+    assert np.array_equal(np.concatenate(outs, axis=1), got)
