@@ -25,7 +25,7 @@ DSP_DEV c32 unit_root_wide(unsigned long long num, int log2den) {
     // exponents here reach 2^30 and more: evaluate the angle in double (exact dyadic fraction)
     double sn, cs;
     sincospi(static_cast<double>(num) * __builtin_ldexp(2.0, -log2den), &sn, &cs);
-    return make_float2(static_cast<float>(cs), static_cast<float>(SIGN > 0 ? sn : -sn));
+    return mk(static_cast<float>(cs), static_cast<float>(SIGN > 0 ? sn : -sn));
 }
 
 // two complex values per thread (16-byte accesses); C is even
@@ -45,7 +45,7 @@ __global__ __launch_bounds__(kDistThreads) void swap_axes_kernel(const float4 *_
             const unsigned long long row = row0 + b;
             const c32 w0 = unit_root_wide<SIGN>((row * col) & mask, tw_log2);
             const c32 w1 = unit_root_wide<SIGN>((row * (col + 1)) & mask, tw_log2);
-            const c32 p0 = cmul(make_float2(v.x, v.y), w0), p1 = cmul(make_float2(v.z, v.w), w1);
+            const c32 p0 = cmul(mk(v.x, v.y), w0), p1 = cmul(mk(v.z, v.w), w1);
             v = make_float4(p0.x, p0.y, p1.x, p1.y);
         }
         out[(b * A + a) * C2 + c2] = v;
@@ -77,8 +77,10 @@ __global__ __launch_bounds__(kDistThreads) void transpose_blocks_kernel(const c3
 
 }  // namespace
 
-int launch_swap_axes(const float2 *in, float2 *out, size_t a, size_t b, size_t c, int tw_log2, unsigned long long row0,
+int launch_swap_axes(const float2 *in_f2, float2 *out_f2, size_t a, size_t b, size_t c, int tw_log2, unsigned long long row0,
                      int direction, hipStream_t s) {
+    const c32 *in = reinterpret_cast<const c32 *>(in_f2);
+    c32 *out = reinterpret_cast<c32 *>(out_f2);
     if (c % 2) return fail(DSP_GPU_EINVAL, "swap_axes: inner extent %zu must be even", c);
     const size_t total = a * b * (c / 2);
     if (total == 0) return DSP_GPU_OK;
@@ -94,7 +96,9 @@ int launch_swap_axes(const float2 *in, float2 *out, size_t a, size_t b, size_t c
     return check_launch("swap_axes_kernel");
 }
 
-int launch_transpose_blocks(const float2 *in, float2 *out, size_t blocks, size_t rows, size_t cols, hipStream_t s) {
+int launch_transpose_blocks(const float2 *in_f2, float2 *out_f2, size_t blocks, size_t rows, size_t cols, hipStream_t s) {
+    const c32 *in = reinterpret_cast<const c32 *>(in_f2);
+    c32 *out = reinterpret_cast<c32 *>(out_f2);
     const size_t tiles = blocks * ((rows + 31) / 32) * ((cols + 31) / 32);
     if (tiles == 0) return DSP_GPU_OK;
     if (tiles > 0x7fffffffull) return fail(DSP_GPU_EUNSUPPORTED, "transpose_blocks: grid too large");

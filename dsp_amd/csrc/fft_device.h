@@ -12,14 +12,21 @@
 
 namespace dspgpu {
 
-using c32 = float2;
 #define DSP_DEV __device__ __forceinline__
+#define DSP_DEV_EARLY __host__ __device__ __forceinline__
+
+// Native 2-vector, not HIP's float2 struct: its + - * are <2 x float> operations, which the backend maps 1:1
+// onto v_pk_add/mul/fma_f32 with the (re, im) pair in one register pair and swaps/negations folded into
+// op_sel/neg modifiers.  With the struct, the SLP vectoriser paired up unrelated scalars and a third of the
+// FFT's VALU instructions were v_mov shuffles.
+typedef float c32 __attribute__((ext_vector_type(2)));
+DSP_DEV_EARLY c32 mk(float x, float y) { return c32{x, y}; }
 
 // Streaming (use-once) global accesses: non-temporal loads and stores measured +3 % on a 2 GiB -> 2 GiB
 // copy with this kernel's access pattern (scripts/copy_patterns2.hip).
 DSP_DEV c32 load_stream(const c32 *p) {
     const float *q = reinterpret_cast<const float *>(p);
-    return make_float2(__builtin_nontemporal_load(q), __builtin_nontemporal_load(q + 1));
+    return mk(__builtin_nontemporal_load(q), __builtin_nontemporal_load(q + 1));
 }
 DSP_DEV void store_stream(c32 *p, c32 v) {
     float *q = reinterpret_cast<float *>(p);
@@ -33,15 +40,41 @@ DSP_DEV void store_stream(c32 *p, c32 v) {
 // Speed only; any placement gives the same result.  Launch 8 * chunk workgroups, skip tiles >= count.
 DSP_DEV size_t xcd_tile(unsigned block, size_t chunk) { return static_cast<size_t>(block & 7u) * chunk + (block >> 3); }
 
-DSP_DEV c32 cadd(c32 a, c32 b) { return make_float2(a.x + b.x, a.y + b.y); }
-DSP_DEV c32 csub(c32 a, c32 b) { return make_float2(a.x - b.x, a.y - b.y); }
-DSP_DEV c32 cmul(c32 a, c32 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+DSP_DEV c32 cadd(c32 a, c32 b) { return a + b; }
+DSP_DEV c32 csub(c32 a, c32 b) { return a - b; }
+// Complex product in two packed instructions.  The swap and the negation ride on the op_sel / neg
+// modifiers (lo result: a.x*b.x then -a.y*b.y + lo; hi result: a.y*b.x then a.x*b.y + hi); written as
+// asm because the backend otherwise spends a v_xor and two v_mov per product on them.
+DSP_DEV c32 cmul(c32 a, c32 b) {
+    c32 t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "v"(b));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(a), "v"(b), "v"(t));
+    return r;
+}
+
+// the same with a compile-time constant b held in a scalar register pair (no VGPRs, no v_mov)
+DSP_DEV c32 cmul_k(c32 a, c32 b) {
+    c32 t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "s"(b));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(a), "s"(b), "v"(t));
+    return r;
+}
+
+// a + (SIGN i) b in one v_pk_add_f32: lo = a.x -/+ b.y, hi = a.y +/- b.x
+template <int SIGN>
+DSP_DEV c32 add_mul_i(c32 a, c32 b) {
+    c32 r;
+    if constexpr (SIGN > 0)
+        asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    else
+        asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 
 // multiply by SIGN * i
 template <int SIGN>
 DSP_DEV c32 mul_i(c32 a) {
-    if constexpr (SIGN > 0) return make_float2(-a.y, a.x);
-    else return make_float2(a.y, -a.x);
+    return add_mul_i<SIGN>(c32{0.0f, 0.0f}, a);
 }
 
 constexpr float cos16(int q) {
@@ -59,12 +92,12 @@ DSP_DEV c32 mul_w16(c32 a) {
     constexpr int q = ((Q % 16) + 16) % 16;
     if constexpr (q == 0) return a;
     else if constexpr (q == 4) return mul_i<SIGN>(a);
-    else if constexpr (q == 8) return make_float2(-a.x, -a.y);
+    else if constexpr (q == 8) return -a;
     else if constexpr (q == 12) return mul_i<-SIGN>(a);
     else {
         constexpr float c = cos16(q);
         constexpr float s = SIGN * sin16(q);
-        return make_float2(a.x * c - a.y * s, a.x * s + a.y * c);
+        return cmul_k(a, c32{c, s});
     }
 }
 
@@ -78,11 +111,11 @@ DSP_DEV void dft2(c32 &a, c32 &b) {
 // natural-order 4-point DFT with W4 = SIGN*i
 template <int SIGN>
 DSP_DEV void dft4(c32 &a, c32 &b, c32 &c, c32 &d) {
-    const c32 t0 = cadd(a, c), t1 = csub(a, c), t2 = cadd(b, d), t3 = mul_i<SIGN>(csub(b, d));
+    const c32 t0 = cadd(a, c), t1 = csub(a, c), t2 = cadd(b, d), t3 = csub(b, d);
     a = cadd(t0, t2);
-    b = cadd(t1, t3);
+    b = add_mul_i<SIGN>(t1, t3);
     c = csub(t0, t2);
-    d = csub(t1, t3);
+    d = add_mul_i<-SIGN>(t1, t3);
 }
 
 // In-register DFT of v[0..R), natural order in and out.
@@ -159,7 +192,7 @@ template <int SIGN>
 DSP_DEV c32 unit_root(unsigned num, int log2den) {
     float sn, cs;
     sincospif(static_cast<float>(num) * __builtin_ldexpf(2.0f, -log2den), &sn, &cs);
-    return make_float2(cs, SIGN > 0 ? sn : -sn);
+    return mk(cs, SIGN > 0 ? sn : -sn);
 }
 
 // One Stockham pass on the P register-resident points of a thread.

@@ -49,7 +49,7 @@ __global__ __launch_bounds__(kThreads) void fft_lds_kernel(const void *__restric
 #pragma unroll
             for (int m = 0; m < kPoints; ++m) {
                 const size_t i = lt + T * m;
-                r[m] = make_float2(i < n_in ? src[i] : 0.0f, 0.0f);
+                r[m] = mk(i < n_in ? src[i] : 0.0f, 0.0f);
             }
         } else {
             const c32 *src = static_cast<const c32 *>(in_) + xf * N;
@@ -58,7 +58,7 @@ __global__ __launch_bounds__(kThreads) void fft_lds_kernel(const void *__restric
         }
     } else {
 #pragma unroll
-        for (int m = 0; m < kPoints; ++m) r[m] = make_float2(0.0f, 0.0f);
+        for (int m = 0; m < kPoints; ++m) r[m] = mk(0.0f, 0.0f);
     }
 
     fft_passes<LOG2N, SIGN>(r, lds, lt, g * N);
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(kThreads) void fft_tiny_kernel(const void *__restri
     if constexpr (REAL_IN) {
         const float *src = static_cast<const float *>(in_) + xf * in_stride;
 #pragma unroll
-        for (int m = 0; m < N; ++m) v[m] = make_float2(static_cast<size_t>(m) < n_in ? src[m] : 0.0f, 0.0f);
+        for (int m = 0; m < N; ++m) v[m] = mk(static_cast<size_t>(m) < n_in ? src[m] : 0.0f, 0.0f);
     } else {
         const c32 *src = static_cast<const c32 *>(in_) + xf * N;
 #pragma unroll
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(kThreads) void pack_real_kernel(const float *__rest
     for (size_t i = static_cast<size_t>(blockIdx.x) * kThreads + threadIdx.x; i < total;
          i += static_cast<size_t>(gridDim.x) * kThreads) {
         const size_t row = i / n, col = i % n;
-        out[i] = make_float2(col < n_in ? in[row * in_stride + col] : 0.0f, 0.0f);
+        out[i] = mk(col < n_in ? in[row * in_stride + col] : 0.0f, 0.0f);
     }
 }
 
@@ -296,7 +296,9 @@ int launch_large(const c32 *in, c32 *out, int log2n, size_t batch, int direction
 
 }  // namespace
 
-int launch_fft_batch(const float2 *in, float2 *out, int log2n, size_t batch, int direction, hipStream_t s) {
+int launch_fft_batch(const float2 *in_f2, float2 *out_f2, int log2n, size_t batch, int direction, hipStream_t s) {
+    const c32 *in = reinterpret_cast<const c32 *>(in_f2);
+    c32 *out = reinterpret_cast<c32 *>(out_f2);
     if (batch == 0) return DSP_GPU_OK;
     if (log2n <= 12) return dispatch_small<false, false>(log2n, in, out, batch, 0, 0, direction, s);
     return launch_large(in, out, log2n, batch, direction, s);
@@ -306,7 +308,9 @@ int launch_fft_batch(const float2 *in, float2 *out, int log2n, size_t batch, int
 //   n <= 256: one column pass.  Otherwise n = na*nb:
 //   pass 1  [na][nb*cols]   FFT over na, twiddle W_n^{ka*nb_index}, store -> [nb][ka][cols]
 //   pass 2  [nb][ka*cols]   FFT over nb                              -> [kb][ka][cols] = [k][cols]
-int launch_fft_columns(const float2 *in, float2 *out, int log2n, size_t cols, int direction, hipStream_t s) {
+int launch_fft_columns(const float2 *in_f2, float2 *out_f2, int log2n, size_t cols, int direction, hipStream_t s) {
+    const c32 *in = reinterpret_cast<const c32 *>(in_f2);
+    c32 *out = reinterpret_cast<c32 *>(out_f2);
     if (log2n < 4 || log2n > 16) return fail(DSP_GPU_EINVAL, "fft_columns: log2n %d outside [4,16]", log2n);
     if (in == out) return fail(DSP_GPU_EINVAL, "fft_columns: in-place is not supported");
     if (log2n <= 8) {
@@ -326,8 +330,9 @@ int launch_fft_columns(const float2 *in, float2 *out, int log2n, size_t cols, in
     return launch_column(lb, scratch, out, p2, 1, direction, s);
 }
 
-int launch_fft_real_batch(const float *in, size_t n_in, size_t in_stride, float2 *out, int log2n, size_t batch,
+int launch_fft_real_batch(const float *in, size_t n_in, size_t in_stride, float2 *out_f2, int log2n, size_t batch,
                           int direction, int shifted, hipStream_t s) {
+    c32 *out = reinterpret_cast<c32 *>(out_f2);
     if (batch == 0) return DSP_GPU_OK;
     if (log2n <= 12) {
         if (shifted) return dispatch_small<true, true>(log2n, in, out, batch, n_in, in_stride, direction, s);

@@ -175,13 +175,23 @@ __global__ __launch_bounds__(kThreads) void fir_overlap_save_kernel(const float 
     const float *hc = hist ? hist + ch * order : nullptr;
     const long long in_a = static_cast<long long>(2 * pair) * L, in_b = in_a + L;
 
+    // interior pairs (all but the first of a streamed chunk and the last one or two of a channel) take
+    // the unchecked path: the bounds handling costs more VALU work than a radix-16 pass
+    const bool interior = in_a >= hoff && in_b + kOsN <= nn;
     c32 r[kPoints];
+    if (interior) {
+        const float *pa = xc + in_a + tid, *pb = pa + L;
 #pragma unroll
-    for (int m = 0; m < kPoints; ++m) {
-        const long long ia = in_a + tid + kThreads * m, ib = in_b + tid + kThreads * m;
-        const float va = ia >= nn ? 0.0f : (ia >= hoff ? __builtin_nontemporal_load(xc + ia) : hc[ia]);
-        const float vb = ib >= nn ? 0.0f : (ib >= hoff ? __builtin_nontemporal_load(xc + ib) : hc[ib]);
-        r[m] = make_float2(va, vb);
+        for (int m = 0; m < kPoints; ++m)
+            r[m] = mk(__builtin_nontemporal_load(pa + kThreads * m), __builtin_nontemporal_load(pb + kThreads * m));
+    } else {
+#pragma unroll
+        for (int m = 0; m < kPoints; ++m) {
+            const long long ia = in_a + tid + kThreads * m, ib = in_b + tid + kThreads * m;
+            const float va = ia >= nn ? 0.0f : (ia >= hoff ? __builtin_nontemporal_load(xc + ia) : hc[ia]);
+            const float vb = ib >= nn ? 0.0f : (ib >= hoff ? __builtin_nontemporal_load(xc + ib) : hc[ib]);
+            r[m] = mk(va, vb);
+        }
     }
     fft_passes<kOsLog2N, +1>(r, lds, tid, 0);
     constexpr float scale = 1.0f / kOsN;
@@ -189,13 +199,24 @@ __global__ __launch_bounds__(kThreads) void fir_overlap_save_kernel(const float 
     for (int m = 0; m < kPoints; ++m) {
         const c32 h = hspec[tid + kThreads * m];
         const c32 v = cmul(r[m], h);
-        r[m] = make_float2(v.x * scale, v.y * scale);
+        r[m] = mk(v.x * scale, v.y * scale);
     }
     __syncthreads();  // the forward passes' last LDS image has been read by everyone
     fft_passes<kOsLog2N, -1>(r, lds, tid, 0);
 
     if (pair == 0 && !hist)  // filter.h:126,133: the first `order` outputs of the channel stay zero
         for (long long j = tid; j < order && j < nn; j += kThreads) yc[j] = 0.0f;
+    if (interior) {  // every kept output is in range and past the zero head
+        float *pa = yc + in_a + tid, *pb = pa + L;
+        const int ord = static_cast<int>(order);
+#pragma unroll
+        for (int m = 0; m < kPoints; ++m) {
+            if (tid + kThreads * m < ord) continue;  // wrapped (circular) part of the block
+            __builtin_nontemporal_store(r[m].x, pa + kThreads * m);
+            __builtin_nontemporal_store(r[m].y, pb + kThreads * m);
+        }
+        return;
+    }
 #pragma unroll
     for (int m = 0; m < kPoints; ++m) {
         const long long k = tid + kThreads * m;
@@ -372,14 +393,16 @@ int launch_fir_direct(const float *x, float *y, size_t channels, size_t n, const
     return check_launch("fir_direct_kernel");
 }
 
-int launch_fir_spectrum(const float *d_taps, int ntaps, float2 *d_hspec, hipStream_t s) {
+int launch_fir_spectrum(const float *d_taps, int ntaps, float2 *d_hspec_f2, hipStream_t s) {
+    c32 *d_hspec = reinterpret_cast<c32 *>(d_hspec_f2);
     // FORWARD transform of the taps zero padded to 4096 points (the real-input wrapper does the padding)
-    return launch_fft_real_batch(d_taps, static_cast<size_t>(ntaps), static_cast<size_t>(ntaps), d_hspec, kOsLog2N, 1,
+    return launch_fft_real_batch(d_taps, static_cast<size_t>(ntaps), static_cast<size_t>(ntaps), d_hspec_f2, kOsLog2N, 1,
                                  DSP_GPU_FORWARD, 0, s);
 }
 
-int launch_fir_overlap_save(const float *x, float *y, size_t channels, size_t n, const float2 *d_hspec, int ntaps,
+int launch_fir_overlap_save(const float *x, float *y, size_t channels, size_t n, const float2 *d_hspec_f2, int ntaps,
                             const float *hist, int zero_head, hipStream_t s) {
+    const c32 *d_hspec = reinterpret_cast<const c32 *>(d_hspec_f2);
     const long long order = ntaps - 1;
     const long long L = kOsN - order;
     const long long nv = static_cast<long long>(n) + (hist ? order : 0);  // length of the (virtual) signal
