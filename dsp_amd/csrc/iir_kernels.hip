@@ -80,7 +80,7 @@ DSP_DEV void run_row_partial(float *row, int count, double (&xh)[P], double (&vh
 // ---------------------------------------------------------------------------------------------
 // batch: one lane per channel
 // ---------------------------------------------------------------------------------------------
-constexpr int kBt = 64;          // samples per tile row
+constexpr int kBt = 128;         // samples per tile row: 512-byte row segments (256-byte ones cap a plain copy at 4.4 TB/s, scripts/copy_patterns3.hip)
 constexpr int kBtPad = kBt + 1;  // conflict-free row walk
 constexpr int kBtIters = kBt * kWave / (kWave * 4);  // float4 loads per lane per tile = 16
 
