@@ -292,51 +292,59 @@ __global__ __launch_bounds__(kThreads) void moving_average_kernel(const float *_
     }
     __syncthreads();
 
-    // thread t owns chunks [t*cpt, (t+1)*cpt): in-chunk exclusive prefixes (float, in place) + chunk sums
-    const int c0 = tid * cpt;
-    double mine = 0.0;
-    for (int k = 0; k < cpt; ++k) {
-        const int c = c0 + k;
-        if (c >= chunks) break;
-        float run = 0.0f;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            float4 *p = reinterpret_cast<float4 *>(xs + ma_pad(16 * c + 4 * q));
-            const float4 v = *p;
-            float4 e;
-            e.x = run;
-            e.y = e.x + v.x;
-            e.z = e.y + v.y;
-            e.w = e.z + v.z;
-            run = e.w + v.w;
-            *p = e;
-        }
-        pc[c] = static_cast<double>(run);  // chunk total for now
-        mine += static_cast<double>(run);
-    }
-    // block-wide exclusive scan of the per-thread totals in double
-    double incl = mine;
+    // round k: thread t owns chunk t + 256*k (consecutive lanes on consecutive chunks: the 20-dword lane
+    // stride keeps the 16-byte LDS accesses conflict-free).  In-chunk exclusive prefixes (float, in place),
+    // then a block-wide exclusive scan of the chunk totals in double, rounds chained through `base`.
     const int lane = tid & 63, wave = tid >> 6;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const double o = shfl_up_f64(incl, d);
-        if (lane >= d) incl += o;
-    }
-    if (lane == 63) wave_tot[wave] = incl;
-    __syncthreads();
-    double running = incl - mine;
-    for (int w = 0; w < wave; ++w) running += wave_tot[w];
+    double base = 0.0;
     for (int k = 0; k < cpt; ++k) {
-        const int c = c0 + k;
-        if (c >= chunks) break;
-        const double total = pc[c];
-        pc[c] = running;  // exclusive prefix of the chunk sums
-        running += total;
+        const int c = tid + kThreads * k;
+        float run = 0.0f;
+        if (c < chunks) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float4 *p = reinterpret_cast<float4 *>(xs + ma_pad(16 * c + 4 * q));
+                const float4 v = *p;
+                float4 e;
+                e.x = run;
+                e.y = e.x + v.x;
+                e.z = e.y + v.y;
+                e.w = e.z + v.z;
+                run = e.w + v.w;
+                *p = e;
+            }
+        }
+        const double mine = static_cast<double>(run);
+        double incl = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const double o = shfl_up_f64(incl, d);
+            if (lane >= d) incl += o;
+        }
+        if (lane == 63) wave_tot[4 * k + wave] = incl;
+        __syncthreads();
+        double running = base + (incl - mine);
+        for (int w = 0; w < wave; ++w) running += wave_tot[4 * k + w];
+        if (c < chunks) pc[c] = running;  // exclusive prefix of the chunk sums
+        base += wave_tot[4 * k] + wave_tot[4 * k + 1] + wave_tot[4 * k + 2] + wave_tot[4 * k + 3];
     }
     __syncthreads();
 
     const double inv = 1.0 / static_cast<double>(npoints);
+    const double dcorr = static_cast<double>(corr);
     const long long hi = (nn - mid > mid + 1) ? nn - mid : mid + 1;  // out[mid] is always written (filter.h:93)
+    if (out0 >= mid && out0 + kMaTile <= hi) {  // interior tile: every output has its full window
+        float *yt = yc + out0;
+#pragma unroll
+        for (int i = 0; i < kMaPer; ++i) {
+            const int jrel = kThreads * i + tid;
+            const int lo = jrel + shift, up = lo + window;  // window = staged samples [lo, up)
+            const double sum = (pc[up >> 4] - pc[lo >> 4]) +
+                               (static_cast<double>(xs[ma_pad(up)]) - static_cast<double>(xs[ma_pad(lo)]));
+            __builtin_nontemporal_store(static_cast<float>((sum - dcorr) * inv), yt + jrel);
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < kMaPer; ++i) {
         const int jrel = kThreads * i + tid;
@@ -344,10 +352,10 @@ __global__ __launch_bounds__(kThreads) void moving_average_kernel(const float *_
         if (j >= nn) continue;
         float v = 0.0f;
         if (j >= mid && j < hi) {
-            const int lo = jrel + shift, up = lo + window;  // window = staged samples [lo, up)
+            const int lo = jrel + shift, up = lo + window;
             const double sum = (pc[up >> 4] - pc[lo >> 4]) +
                                (static_cast<double>(xs[ma_pad(up)]) - static_cast<double>(xs[ma_pad(lo)]));
-            v = static_cast<float>((sum - static_cast<double>(corr)) * inv);
+            v = static_cast<float>((sum - dcorr) * inv);
         }
         __builtin_nontemporal_store(v, yc + j);
     }
@@ -426,7 +434,7 @@ int launch_moving_average(const float *x, float *y, size_t channels, size_t n, i
     const int span = ((kMaTile + window + 4 + 15) / 16) * 16;
     const int chunks = span / 16;
     const int cpt = (chunks + kThreads - 1) / kThreads;
-    const size_t lds_bytes = static_cast<size_t>(span + (span / 16) * 4) * sizeof(float) + static_cast<size_t>(chunks + 4) * sizeof(double);
+    const size_t lds_bytes = static_cast<size_t>(span + (span / 16) * 4) * sizeof(float) + static_cast<size_t>(chunks + 4 * cpt) * sizeof(double);
     const size_t blocks = (n + kMaTile - 1) / kMaTile;
     const bool aligned = (n % 4 == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0);
     auto kern = aligned ? moving_average_kernel<true> : moving_average_kernel<false>;
