@@ -186,6 +186,7 @@ constexpr int kRow = 32;            // samples per row
 constexpr int kRowPad = kRow + 1;
 constexpr int kTile = kSt * kRow;   // 8192 samples per workgroup
 constexpr int kLevels = 8;          // log2(kSt)
+constexpr unsigned kScanWgsPerCu = 4; // resident workgroups per CU (34 KB of LDS each)
 
 enum ScanMode { SCAN_REDUCE = 0, SCAN_APPLY = 1, SCAN_FUSED = 2 };
 
@@ -325,46 +326,62 @@ __global__ __launch_bounds__(kSt) void iir_scan_kernel(const float *__restrict__
                                                        const double *__restrict__ state_in,
                                                        double *__restrict__ state_out, double *__restrict__ tile_z,
                                                        const double *__restrict__ tile_c, unsigned ntiles, int warm,
-                                                       int levels) {
+                                                       int levels, const double *__restrict__ hrow) {
     constexpr int W = kWords<P, WIDE>;
     constexpr int MS = W * P;
     __shared__ float xs[(kSt + 1) * kRowPad];
     __shared__ double sbuf[4 * W];  // wave aggregates
     const int tid = threadIdx.x;
-    const unsigned tile = static_cast<unsigned>(xcd_tile_of(blockIdx.x, (ntiles + 7u) / 8u));  // contiguous time range per XCD
-    if (tile >= ntiles) return;
     const size_t ch = blockIdx.y;
     const float *xc = x + ch * n;
     float *yc = y + ch * n;
     const double *sin_c = state_in ? state_in + ch * 2 * P : nullptr;
+    // Persistent workgroups: XCD x = blockIdx.x & 7 owns the contiguous tile range [x*chunk, (x+1)*chunk) and its
+    // workgroups take those tiles round-robin, loading the NEXT tile's samples into registers while the
+    // current one is scanned (a tile's life was mostly waiting: SQ_WAIT_ANY 0.61 of wave cycles).
+    const unsigned chunk = (ntiles + 7u) / 8u, wgs_per_xcd = gridDim.x >> 3;
+    const unsigned t_lo = (blockIdx.x & 7u) * chunk, t_hi = min(ntiles, t_lo + chunk);
+    unsigned tile = t_lo + (blockIdx.x >> 3);
+    if (tile >= t_hi) return;
 
     // tile geometry: samples [start, start + kTile), outputs kept from out_begin on
-    size_t start, out_begin;
-    if (MODE == SCAN_FUSED && tile > 0) {
-        out_begin = static_cast<size_t>(kTile) + static_cast<size_t>(tile - 1) * (kTile - warm);
-        start = out_begin - warm;
-    } else {
-        start = static_cast<size_t>(tile) * kTile;
-        out_begin = start;
-    }
+    auto tile_start = [&](unsigned tl) -> size_t {
+        if (MODE == SCAN_FUSED && tl > 0) return static_cast<size_t>(kTile) + static_cast<size_t>(tl - 1) * (kTile - warm) - warm;
+        return static_cast<size_t>(tl) * kTile;
+    };
+    constexpr int kPre = kTile / (kSt * 4);  // float4 loads per thread per tile = 8
+    auto tile_load = [&](float4 (&pre)[kPre], size_t start) {
+#pragma unroll
+        for (int q = 0; q < kPre; ++q) {
+            const size_t g = start + static_cast<size_t>(tid * 4 + q * kSt * 4);
+            float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (ALIGNED && g + 3 < n) {
+                v = load_stream_f4(xc + g);
+            } else {
+                if (g < n) v.x = xc[g];
+                if (g + 1 < n) v.y = xc[g + 1];
+                if (g + 2 < n) v.z = xc[g + 2];
+                if (g + 3 < n) v.w = xc[g + 3];
+            }
+            pre[q] = v;
+        }
+    };
+    float4 pre[kPre];
+    tile_load(pre, tile_start(tile));
+
+    for (; tile < t_hi; tile += wgs_per_xcd) {
+    const size_t start = tile_start(tile);
+    const size_t out_begin = (MODE == SCAN_FUSED && tile > 0) ? start + warm : start;
 
     // stage the tile (zeros past the end of the channel) and the P samples of history before it
-    for (int u = tid * 4; u < kTile; u += kSt * 4) {
-        const size_t g = start + u;
-        float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (ALIGNED && g + 3 < n) {
-            v = load_stream_f4(xc + g);
-        } else {
-            if (g < n) v.x = xc[g];
-            if (g + 1 < n) v.y = xc[g + 1];
-            if (g + 2 < n) v.z = xc[g + 2];
-            if (g + 3 < n) v.w = xc[g + 3];
-        }
+#pragma unroll
+    for (int q = 0; q < kPre; ++q) {
+        const int u = tid * 4 + q * kSt * 4;
         float *dst = xs + (u / kRow + 1) * kRowPad + (u % kRow);
-        dst[0] = v.x;
-        dst[1] = v.y;
-        dst[2] = v.z;
-        dst[3] = v.w;
+        dst[0] = pre[q].x;
+        dst[1] = pre[q].y;
+        dst[2] = pre[q].z;
+        dst[3] = pre[q].w;
     }
     if (tid < P) {  // row "-1", column 31 - i holds x[start - 1 - i]
         float h = 0.0f;
@@ -373,19 +390,26 @@ __global__ __launch_bounds__(kSt) void iir_scan_kernel(const float *__restrict__
         xs[kRow - 1 - tid] = h;
     }
     __syncthreads();
+    if (tile + wgs_per_xcd < t_hi) tile_load(pre, tile_start(tile + wgs_per_xcd));  // in flight during the scan
 
     float *row = xs + (tid + 1) * kRowPad;
     double xh0[P], xh[P], vh[P];
 #pragma unroll
     for (int i = 0; i < P; ++i) xh0[i] = static_cast<double>(xs[tid * kRowPad + kRow - 1 - i]);
+    __syncthreads();  // phase A overwrites the rows: every lane has its x history (the row before's tail) first
 
-    // phase A: zero feedback state
+    // phase A: zero feedback state.  Rows other than the one holding the channel's last sample overwrite
+    // their samples with the zero-state OUTPUT (fp32): phase C then only adds the start state's
+    // contribution instead of running the recursion a second time.
+    const size_t g0 = start + static_cast<size_t>(tid) * kRow;
+    const bool last_row = g0 < n && n <= g0 + kRow;
 #pragma unroll
     for (int i = 0; i < P; ++i) {
         xh[i] = xh0[i];
         vh[i] = 0.0;
     }
-    run_row<P, kRow, false>(row, xh, vh, co);
+    if (MODE == SCAN_REDUCE || last_row) run_row<P, kRow, false>(row, xh, vh, co);
+    else run_row<P, kRow, true>(row, xh, vh, co);
     SVec<P, WIDE> S;
     sv_zero<P, WIDE>(S);
 #pragma unroll
@@ -428,7 +452,7 @@ __global__ __launch_bounds__(kSt) void iir_scan_kernel(const float *__restrict__
     }
     if (MODE == SCAN_REDUCE) {
         if (tid == kSt - 1) sv_store<P, WIDE>(S, tile_z + (ch * ntiles + tile) * W);
-        return;
+        continue;  // the barrier above ordered this tile's last LDS reads before the next tile's staging
     }
 
     // phase C: true start state = inclusive state of the row before (the carry for the first row of a
@@ -443,18 +467,25 @@ __global__ __launch_bounds__(kSt) void iir_scan_kernel(const float *__restrict__
             vh[i] = ph + pl;
         }
     }
-    const size_t g0 = start + static_cast<size_t>(tid) * kRow;
-    if (g0 + kRow <= n) {
-        run_row<P, kRow, true>(row, xh, vh, co);
-    } else if (g0 < n) {
+    if (last_row) {  // the exact recursion from the true start state; also yields the state handed back
         run_row_partial<P, true>(row, static_cast<int>(n - g0), xh, vh, co);
-    }
-    if (state_out && g0 < n && n <= g0 + kRow) {  // this row holds the channel's last sample
-        double *so = state_out + ch * 2 * P;
+        if (state_out) {
+            double *so = state_out + ch * 2 * P;
 #pragma unroll
-        for (int i = 0; i < P; ++i) {
-            so[i] = xh[i];
-            so[P + i] = vh[i];
+            for (int i = 0; i < P; ++i) {
+                so[i] = xh[i];
+                so[P + i] = vh[i];
+            }
+        }
+    } else if (g0 < n) {
+        // v[t] = v_zero_state[t] + sum_i hrow[t][i] * v[-1-i]: hrow[t] is the first row of A^(t+1) (host, from
+        // the recursion run on unit states), uniform across lanes (scalar loads), no loop-carried dependency
+#pragma unroll
+        for (int t = 0; t < kRow; ++t) {
+            double corr = 0.0;
+#pragma unroll
+            for (int i = 0; i < P; ++i) corr = fma(hrow[t * P + i], vh[i], corr);
+            row[t] = static_cast<float>(fma(corr, co.c0, static_cast<double>(row[t])));
         }
     }
     __syncthreads();
@@ -472,6 +503,8 @@ __global__ __launch_bounds__(kSt) void iir_scan_kernel(const float *__restrict__
             if (g + 3 < n) yc[g + 3] = src[3];
         }
     }
+    __syncthreads();  // the tile has been read out before the next one is staged
+    }  // tile loop
 }
 
 // Exclusive scan of the tile end states: C_0 = initial state, C_k = Z_{k-1} + MT C_{k-1}.
@@ -610,10 +643,12 @@ double feedback_noise_gain(const IirCoef &co) {
 
 template <int P, bool ALIGNED, bool WIDE>
 int scan_launch(const float *x, float *y, size_t channels, size_t n, const IirCoef &co, const double *state_in,
-                double *state, const std::vector<Mat> &pow32, const Mat &A, int levels, int warm, hipStream_t s) {
+                double *state, const std::vector<Mat> &pow32, const std::vector<double> &hrow, int levels, int warm,
+                hipStream_t s) {
     constexpr int W = kWords<P, WIDE>;
     const size_t ms = static_cast<size_t>(W) * P;
-    std::vector<double> table(static_cast<size_t>(9 + 9) * ms, 0.0);
+    std::vector<double> table(static_cast<size_t>(9 + 9) * ms + hrow.size(), 0.0);  // 18 matrix slots, then hrow[32][P]
+    std::copy(hrow.begin(), hrow.end(), table.begin() + 18 * ms);
     for (int j = 0; j <= kLevels; ++j) store_mat(table, j, pow32[j], P, WIDE);
     const Mat &MT = pow32[kLevels];  // A^8192
     const bool fused = warm > 0 || n <= static_cast<size_t>(kTile);
@@ -630,17 +665,17 @@ int scan_launch(const float *x, float *y, size_t channels, size_t n, const IirCo
             mg = mat_mul(mg, mg, P);
         }
     }
-    (void)A;
     void *d_table_v = nullptr;
     if (int rc = workspace(WS_IIR_TABLE, table.size() * sizeof(double), &d_table_v)) return rc;
     double *d_table = static_cast<double *>(d_table_v);
     // pageable source: the runtime stages the bytes before returning, `table` may go out of scope
     DSPGPU_HIP(hipMemcpyAsync(d_table, table.data(), table.size() * sizeof(double), hipMemcpyHostToDevice, s));
 
-    const dim3 grid(8u * ((ntiles + 7u) / 8u), static_cast<unsigned>(channels));
+    // persistent: at most kScanWgsPerCu workgroups per CU of an XCD (32 CUs), fewer when there are fewer tiles
+    const dim3 grid(8u * std::min((ntiles + 7u) / 8u, 32u * kScanWgsPerCu), static_cast<unsigned>(channels));
     if (fused) {
         hipLaunchKernelGGL((iir_scan_kernel<P, SCAN_FUSED, ALIGNED, WIDE>), grid, dim3(kSt), 0, s, x, y, n, co, d_table,
-                           state_in, state, nullptr, nullptr, ntiles, warm, levels);
+                           state_in, state, nullptr, nullptr, ntiles, warm, levels, d_table + 18 * ms);
         return check_launch("iir_scan_kernel<fused>");
     }
     void *z_v = nullptr, *c_v = nullptr;
@@ -649,13 +684,13 @@ int scan_launch(const float *x, float *y, size_t channels, size_t n, const IirCo
     if (int rc = workspace(WS_SCRATCH_B, carry_bytes, &c_v)) return rc;
     double *tz = static_cast<double *>(z_v), *tc = static_cast<double *>(c_v);
     hipLaunchKernelGGL((iir_scan_kernel<P, SCAN_REDUCE, ALIGNED, WIDE>), grid, dim3(kSt), 0, s, x, y, n, co, d_table,
-                       state_in, nullptr, tz, nullptr, ntiles, 0, levels);
+                       state_in, nullptr, tz, nullptr, ntiles, 0, levels, d_table + 18 * ms);
     if (int rc = check_launch("iir_scan_kernel<reduce>")) return rc;
     hipLaunchKernelGGL((iir_carry_kernel<P, WIDE>), dim3(static_cast<unsigned>(channels)), dim3(kSt), 0, s, tz, tc,
                        d_table + 9 * ms, state_in, ntiles, G);
     if (int rc = check_launch("iir_carry_kernel")) return rc;
     hipLaunchKernelGGL((iir_scan_kernel<P, SCAN_APPLY, ALIGNED, WIDE>), grid, dim3(kSt), 0, s, x, y, n, co, d_table,
-                       state_in, state, nullptr, tc, ntiles, 0, levels);
+                       state_in, state, nullptr, tc, ntiles, 0, levels, d_table + 18 * ms);
     return check_launch("iir_scan_kernel<apply>");
 }
 
@@ -664,6 +699,7 @@ int scan_launch(const float *x, float *y, size_t channels, size_t n, const IirCo
 struct ScanPlan {
     IirCoef co;
     std::vector<Mat> pow32;  // A^(32*2^j), j = 0..8
+    std::vector<double> hrow;  // [32][P]: v[t] of the zero-input run started from the unit state e_i
     int levels = 0;          // doubling levels whose matrix still matters (norm > 2^-60)
     int warm = -1;           // smallest multiple of 32 with ||A^W||_inf <= 2^-44 (<= kTile/8), else -1
     bool wide = false;       // carry states in double-double
@@ -682,6 +718,7 @@ void build_plan(const IirCoef &co, ScanPlan &plan) {
     std::vector<DD> st(static_cast<size_t>(P) * P);  // st[c*P + i] = state component i of the run started from e_c
     for (int c = 0; c < P; ++c)
         for (int i = 0; i < P; ++i) st[c * P + i] = DD{i == c ? 1.0 : 0.0, 0.0};
+    plan.hrow.assign(static_cast<size_t>(kRow) * P, 0.0);
     double amp = 0.0;
     plan.levels = kLevels + 1;
     plan.warm = -1;
@@ -692,6 +729,7 @@ void build_plan(const IirCoef &co, ScanPlan &plan) {
             for (int i = 0; i < P; ++i) v = dd_add(v, dd_mul(DD{co.b[i + 1], 0.0}, st[c * P + i]));
             for (int i = P - 1; i >= 1; --i) st[c * P + i] = st[c * P + i - 1];
             st[c * P] = v;
+            if (k <= kRow) plan.hrow[static_cast<size_t>(k - 1) * P + c] = v.hi + v.lo;
         }
         if (k % kRow) continue;
         double nrm = 0.0;  // ||A^k||_inf: rows are state components, columns the start vectors
@@ -760,9 +798,8 @@ int scan_dispatch(const float *x, float *y, size_t channels, size_t n, const Iir
         DSPGPU_HIP(hipMemcpyAsync(snap, state, sb, hipMemcpyDeviceToDevice, s));
         state_in = static_cast<const double *>(snap);
     }
-    const Mat unused;
-    return plan.wide ? scan_launch<P, ALIGNED, true>(x, y, channels, n, co, state_in, state, plan.pow32, unused, plan.levels, plan.warm, s)
-                     : scan_launch<P, ALIGNED, false>(x, y, channels, n, co, state_in, state, plan.pow32, unused, plan.levels, plan.warm, s);
+    return plan.wide ? scan_launch<P, ALIGNED, true>(x, y, channels, n, co, state_in, state, plan.pow32, plan.hrow, plan.levels, plan.warm, s)
+                     : scan_launch<P, ALIGNED, false>(x, y, channels, n, co, state_in, state, plan.pow32, plan.hrow, plan.levels, plan.warm, s);
 }
 
 template <int P, bool ALIGNED>
