@@ -26,6 +26,7 @@ EXPORTS = (
     "dsp_gpu_convolve_stream",
     "dsp_gpu_moving_average",
     "dsp_gpu_iir",
+    "dsp_gpu_iir_multi",
     "dsp_gpu_device_count",
     "dsp_gpu_last_error_string",
     "dsp_gpu_shutdown",
@@ -62,6 +63,8 @@ def lib() -> C.CDLL:
         L.dsp_gpu_convolve_stream.restype = i
         L.dsp_gpu_moving_average.argtypes = [vp, vp, sz, sz, i, i, vp]
         L.dsp_gpu_iir.argtypes = [vp, vp, sz, sz, vp, vp, i, C.c_double, C.c_double, vp, i, i, vp]
+        L.dsp_gpu_iir_multi.argtypes = [vp, vp, sz, sz, vp, vp, i, vp, vp, vp, i, vp]
+        L.dsp_gpu_iir_multi.restype = i
         L.dsp_gpu_fft_columns.argtypes = [vp, vp, i, sz, i, vp]
         L.dsp_gpu_swap_axes.argtypes = [vp, vp, sz, sz, sz, i, sz, i, vp]
         L.dsp_gpu_transpose_blocks.argtypes = [vp, vp, sz, sz, sz, vp]

@@ -322,7 +322,7 @@ int dsp_gpu_moving_average(const float *x, float *y, size_t channels, size_t n, 
 int dsp_gpu_iir(const float *x, float *y, size_t channels, size_t n, const double *a, const double *b, int poles,
                 double c0, double d0, double *state, int mode, int mem, void *stream) {
     if (!x || !y || !a || !b) return fail(DSP_GPU_EINVAL, "dsp_gpu_iir: null buffer");
-    if (poles < 1 || poles > 8) return fail(DSP_GPU_EINVAL, "dsp_gpu_iir: poles %d outside [1,8]", poles);
+    if (poles < 1 || poles > 20) return fail(DSP_GPU_EINVAL, "dsp_gpu_iir: poles %d outside [1,20]", poles);
     if (mode != DSP_GPU_IIR_AUTO && mode != DSP_GPU_IIR_BATCH && mode != DSP_GPU_IIR_SCAN)
         return fail(DSP_GPU_EINVAL, "dsp_gpu_iir: mode %d", mode);
     if (bad_mem(mem)) return fail(DSP_GPU_EINVAL, "dsp_gpu_iir: mem %d", mem);
@@ -339,7 +339,7 @@ int dsp_gpu_iir(const float *x, float *y, size_t channels, size_t n, const doubl
     if (!std::isfinite(c0) || !std::isfinite(d0)) return fail(DSP_GPU_EINVAL, "dsp_gpu_iir: non-finite c0/d0");
     const bool auto_mode = mode == DSP_GPU_IIR_AUTO;
     if (auto_mode)  // few long channels cannot fill the chip one thread per channel
-        mode = (channels < 8192 && n >= 65536) ? DSP_GPU_IIR_SCAN : DSP_GPU_IIR_BATCH;
+        mode = (channels < 8192 && n >= 65536 && poles <= 8) ? DSP_GPU_IIR_SCAN : DSP_GPU_IIR_BATCH;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t bytes = channels * n * sizeof(float);
     const size_t state_bytes = channels * 2 * static_cast<size_t>(poles) * sizeof(double);
@@ -359,10 +359,62 @@ int dsp_gpu_iir(const float *x, float *y, size_t channels, size_t n, const doubl
         }
     }
     int rc = mode == DSP_GPU_IIR_SCAN ? launch_iir_scan(dx, dy, channels, n, co, dstate, s)
-                                      : launch_iir_batch(dx, dy, channels, n, co, dstate, s);
+                                      : launch_iir_batch(dx, dy, channels, n, co, dstate, nullptr, s);
     if (rc == DSP_GPU_EUNSUPPORTED && auto_mode && mode == DSP_GPU_IIR_SCAN)  // ill-conditioned for the scan
-        rc = launch_iir_batch(dx, dy, channels, n, co, dstate, s);
+        rc = launch_iir_batch(dx, dy, channels, n, co, dstate, nullptr, s);
     if (rc) return rc;
+    if (mem == DSP_GPU_MEM_HOST) {
+        if (state) DSPGPU_HIP(hipMemcpyAsync(state, dstate, state_bytes, hipMemcpyDeviceToHost, s));
+        return stage_out(y, bytes, s, hs);
+    }
+    return DSP_GPU_OK;
+}
+
+int dsp_gpu_iir_multi(const float *x, float *y, size_t channels, size_t n, const double *a, const double *b, int poles,
+                      const double *c0, const double *d0, double *state, int mem, void *stream) {
+    if (!x || !y || !a || !b) return fail(DSP_GPU_EINVAL, "dsp_gpu_iir_multi: null buffer");
+    if (poles < 1 || poles > 8) return fail(DSP_GPU_EINVAL, "dsp_gpu_iir_multi: poles %d outside [1,8]", poles);
+    if (bad_mem(mem)) return fail(DSP_GPU_EINVAL, "dsp_gpu_iir_multi: mem %d", mem);
+    if (channels == 0 || n == 0) return DSP_GPU_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    IirCoef co{};
+    co.poles = poles;
+    const size_t bytes = channels * n * sizeof(float);
+    const size_t state_bytes = channels * 2 * static_cast<size_t>(poles) * sizeof(double);
+    const size_t ab = channels * static_cast<size_t>(poles + 1);  // doubles in a (and in b)
+    const float *dx = x;
+    float *dy = y;
+    double *dstate = state;
+    IirPerChannel pc{a, b, c0, d0};
+    HostStage hs;
+    if (mem == DSP_GPU_MEM_HOST) {
+        for (size_t i = 0; i < ab; ++i)
+            if (!std::isfinite(a[i]) || !std::isfinite(b[i])) return fail(DSP_GPU_EINVAL, "dsp_gpu_iir_multi: non-finite coefficient");
+        if (int rc = stage_in(x, bytes, bytes, s, &hs)) return rc;
+        dx = static_cast<const float *>(hs.d_in);
+        dy = static_cast<float *>(hs.d_out);
+        void *p = nullptr;
+        if (int rc = workspace(WS_SCRATCH_A, (2 * ab + 2 * channels) * sizeof(double), &p)) return rc;
+        double *dc = static_cast<double *>(p);
+        DSPGPU_HIP(hipMemcpyAsync(dc, a, ab * sizeof(double), hipMemcpyHostToDevice, s));
+        DSPGPU_HIP(hipMemcpyAsync(dc + ab, b, ab * sizeof(double), hipMemcpyHostToDevice, s));
+        pc.a = dc;
+        pc.b = dc + ab;
+        if (c0) {
+            DSPGPU_HIP(hipMemcpyAsync(dc + 2 * ab, c0, channels * sizeof(double), hipMemcpyHostToDevice, s));
+            pc.c0 = dc + 2 * ab;
+        }
+        if (d0) {
+            DSPGPU_HIP(hipMemcpyAsync(dc + 2 * ab + channels, d0, channels * sizeof(double), hipMemcpyHostToDevice, s));
+            pc.d0 = dc + 2 * ab + channels;
+        }
+        if (state) {
+            if (int rc = workspace(WS_STATE, state_bytes, &p)) return rc;
+            dstate = static_cast<double *>(p);
+            DSPGPU_HIP(hipMemcpyAsync(dstate, state, state_bytes, hipMemcpyHostToDevice, s));
+        }
+    }
+    if (int rc = launch_iir_batch(dx, dy, channels, n, co, dstate, &pc, s)) return rc;
     if (mem == DSP_GPU_MEM_HOST) {
         if (state) DSPGPU_HIP(hipMemcpyAsync(state, dstate, state_bytes, hipMemcpyDeviceToHost, s));
         return stage_out(y, bytes, s, hs);

@@ -80,13 +80,18 @@ int launch_fir_spectrum(const float *d_taps, int ntaps, float2 *d_hspec, hipStre
 int launch_moving_average(const float *x, float *y, size_t channels, size_t n, int npoints, hipStream_t s);
 
 struct IirCoef {  // a Coefficients<Poles> without its history (coefficients.h:7-15), double as in the reference
-    double a[9];
-    double b[9];
+    double a[21];  // up to Coefficients<20> (recursive_filters.h:30-31 designs 2..20 poles)
+    double b[21];
     double c0, d0;
     int poles;
 };
+// One coefficient set per channel (device pointers): a, b are [channels][poles + 1] (b[.][0] ignored), c0, d0 [channels].
+struct IirPerChannel {
+    const double *a, *b, *c0, *d0;
+};
+// per_channel == nullptr: `co` for every channel; otherwise only co.poles is read from `co` (poles <= 8).
 int launch_iir_batch(const float *x, float *y, size_t channels, size_t n, const IirCoef &co, double *state,
-                     hipStream_t s);
+                     const IirPerChannel *per_channel, hipStream_t s);
 int launch_iir_scan(const float *x, float *y, size_t channels, size_t n, const IirCoef &co, double *state,
                     hipStream_t s);
 

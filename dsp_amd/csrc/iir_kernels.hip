@@ -25,6 +25,7 @@
 #include <cmath>
 #include <cstring>
 #include <mutex>
+#include <type_traits>
 #include <vector>
 
 #include "common.h"
@@ -38,8 +39,14 @@ constexpr int kWave = 64;
 
 // One recursion step.  xh[i] = x[t-1-i], vh[i] = v[t-1-i].  The feedback term through v[t-1] is
 // applied last so the loop-carried dependency is a single fma.
+// C: IirCoef (wave-uniform, read from the kernel arguments) or LaneCoef<P> (one set per lane, in registers).
 template <int P>
-DSP_DEV double iir_step(double x0, double (&xh)[P], double (&vh)[P], const IirCoef &co) {
+struct LaneCoef {
+    double a[P + 1], b[P + 1], c0, d0;
+};
+
+template <int P, typename C>
+DSP_DEV double iir_step(double x0, double (&xh)[P], double (&vh)[P], const C &co) {
     double f = co.a[0] * x0;
 #pragma unroll
     for (int k = 0; k < P; ++k) f = fma(co.a[k + 1], xh[k], f);
@@ -57,8 +64,8 @@ DSP_DEV double iir_step(double x0, double (&xh)[P], double (&vh)[P], const IirCo
 }
 
 // Run `LEN` samples of one LDS row (stride 1).  STORE: overwrite the row with y.
-template <int P, int LEN, bool STORE>
-DSP_DEV void run_row(float *row, double (&xh)[P], double (&vh)[P], const IirCoef &co) {
+template <int P, int LEN, bool STORE, typename C>
+DSP_DEV void run_row(float *row, double (&xh)[P], double (&vh)[P], const C &co) {
 #pragma unroll 16
     for (int i = 0; i < LEN; ++i) {
         const double x0 = static_cast<double>(row[i]);
@@ -67,8 +74,8 @@ DSP_DEV void run_row(float *row, double (&xh)[P], double (&vh)[P], const IirCoef
     }
 }
 
-template <int P, bool STORE>
-DSP_DEV void run_row_partial(float *row, int count, double (&xh)[P], double (&vh)[P], const IirCoef &co) {
+template <int P, bool STORE, typename C>
+DSP_DEV void run_row_partial(float *row, int count, double (&xh)[P], double (&vh)[P], const C &co) {
 #pragma unroll 1
     for (int i = 0; i < count; ++i) {
         const double x0 = static_cast<double>(row[i]);
@@ -109,10 +116,13 @@ DSP_DEV void batch_load(const float *__restrict__ x, size_t channels, size_t n, 
     }
 }
 
-template <int P, bool ALIGNED>
+// P: compiled recursion order; sp <= P: the caller's order (its state is [ch][2*sp]; the top P - sp
+// coefficients are zero, which leaves every sum unchanged).  PERCH: one coefficient set per channel.
+template <int P, bool ALIGNED, bool PERCH>
 __global__ __launch_bounds__(kWave) void iir_batch_kernel(const float *__restrict__ x, float *__restrict__ y,
-                                                           size_t channels, size_t n, IirCoef co,
-                                                           double *__restrict__ state, size_t groups, size_t chunk) {
+                                                           size_t channels, size_t n, IirCoef uco,
+                                                           double *__restrict__ state, size_t groups, size_t chunk,
+                                                           int sp, IirPerChannel pc) {
     __shared__ float tile[kWave * kBtPad];
     constexpr int kLanesPerRow = kBt / 4;
     constexpr int kRowsPerIter = kWave / kLanesPerRow;
@@ -126,8 +136,20 @@ __global__ __launch_bounds__(kWave) void iir_batch_kernel(const float *__restric
     double xh[P], vh[P];
 #pragma unroll
     for (int i = 0; i < P; ++i) {
-        xh[i] = (live && state) ? state[ch * 2 * P + i] : 0.0;
-        vh[i] = (live && state) ? state[ch * 2 * P + P + i] : 0.0;
+        xh[i] = (live && state && i < sp) ? state[ch * 2 * sp + i] : 0.0;
+        vh[i] = (live && state && i < sp) ? state[ch * 2 * sp + sp + i] : 0.0;
+    }
+    typename std::conditional<PERCH, LaneCoef<P>, IirCoef>::type co;
+    if constexpr (PERCH) {
+#pragma unroll
+        for (int i = 0; i <= P; ++i) {
+            co.a[i] = (live && i <= sp) ? pc.a[ch * (sp + 1) + i] : 0.0;
+            co.b[i] = (live && i <= sp && i > 0) ? pc.b[ch * (sp + 1) + i] : 0.0;
+        }
+        co.c0 = pc.c0 ? (live ? pc.c0[ch] : 0.0) : 1.0;  // Coefficients' defaults (coefficients.h:11-12)
+        co.d0 = pc.d0 ? (live ? pc.d0[ch] : 0.0) : 0.0;
+    } else {
+        co = uco;
     }
 
     const size_t ntiles = (n + kBt - 1) / kBt;
@@ -172,8 +194,9 @@ __global__ __launch_bounds__(kWave) void iir_batch_kernel(const float *__restric
     if (live && state) {
 #pragma unroll
         for (int i = 0; i < P; ++i) {
-            state[ch * 2 * P + i] = xh[i];
-            state[ch * 2 * P + P + i] = vh[i];
+            if (i >= sp) break;
+            state[ch * 2 * sp + i] = xh[i];
+            state[ch * 2 * sp + sp + i] = vh[i];
         }
     }
 }
@@ -804,12 +827,20 @@ int scan_dispatch(const float *x, float *y, size_t channels, size_t n, const Iir
 
 template <int P, bool ALIGNED>
 int batch_dispatch(const float *x, float *y, size_t channels, size_t n, const IirCoef &co, double *state,
-                   hipStream_t s) {
+                   const IirPerChannel *pc, hipStream_t s) {
     const size_t groups = (channels + kWave - 1) / kWave;
     const size_t chunk = (groups + 7) / 8;
     if (8 * chunk > 0x7fffffffull) return fail(DSP_GPU_EUNSUPPORTED, "IIR batch: too many channels");
-    hipLaunchKernelGGL((iir_batch_kernel<P, ALIGNED>), dim3(static_cast<unsigned>(8 * chunk)), dim3(kWave), 0, s, x, y,
-                       channels, n, co, state, groups, chunk);
+    const dim3 grid(static_cast<unsigned>(8 * chunk));
+    if constexpr (P <= 8) {
+        if (pc) {
+            hipLaunchKernelGGL((iir_batch_kernel<P, ALIGNED, true>), grid, dim3(kWave), 0, s, x, y, channels, n, co, state,
+                               groups, chunk, co.poles, *pc);
+            return check_launch("iir_batch_kernel<per-channel>");
+        }
+    }
+    hipLaunchKernelGGL((iir_batch_kernel<P, ALIGNED, false>), grid, dim3(kWave), 0, s, x, y, channels, n, co, state, groups,
+                       chunk, co.poles, IirPerChannel{});
     return check_launch("iir_batch_kernel");
 }
 
@@ -819,29 +850,48 @@ bool is_aligned(const float *x, const float *y, size_t n) {
 
 }  // namespace
 
-#define DSP_IIR_SWITCH(FN)                                                                      \
-    switch (co.poles) {                                                                         \
-    case 1: return al ? FN<1, true>(x, y, channels, n, co, state, s) : FN<1, false>(x, y, channels, n, co, state, s); \
-    case 2: return al ? FN<2, true>(x, y, channels, n, co, state, s) : FN<2, false>(x, y, channels, n, co, state, s); \
-    case 3: return al ? FN<3, true>(x, y, channels, n, co, state, s) : FN<3, false>(x, y, channels, n, co, state, s); \
-    case 4: return al ? FN<4, true>(x, y, channels, n, co, state, s) : FN<4, false>(x, y, channels, n, co, state, s); \
-    case 5: return al ? FN<5, true>(x, y, channels, n, co, state, s) : FN<5, false>(x, y, channels, n, co, state, s); \
-    case 6: return al ? FN<6, true>(x, y, channels, n, co, state, s) : FN<6, false>(x, y, channels, n, co, state, s); \
-    case 7: return al ? FN<7, true>(x, y, channels, n, co, state, s) : FN<7, false>(x, y, channels, n, co, state, s); \
-    case 8: return al ? FN<8, true>(x, y, channels, n, co, state, s) : FN<8, false>(x, y, channels, n, co, state, s); \
-    default: return fail(DSP_GPU_EINVAL, "poles %d outside [1,8]", co.poles);                  \
-    }
-
 int launch_iir_batch(const float *x, float *y, size_t channels, size_t n, const IirCoef &co, double *state,
-                     hipStream_t s) {
+                     const IirPerChannel *pc, hipStream_t s) {
     const bool al = is_aligned(x, y, n);
-    DSP_IIR_SWITCH(batch_dispatch)
+    if (pc && co.poles > 8) return fail(DSP_GPU_EUNSUPPORTED, "per-channel IIR coefficients: poles %d > 8", co.poles);
+#define DSP_IIR_BATCH_CASE(P) \
+    return al ? batch_dispatch<P, true>(x, y, channels, n, co, state, pc, s) : batch_dispatch<P, false>(x, y, channels, n, co, state, pc, s)
+    switch (co.poles) {  // orders without a kernel of their own run on the next one up (zero top coefficients)
+    case 1: DSP_IIR_BATCH_CASE(1);
+    case 2: DSP_IIR_BATCH_CASE(2);
+    case 3: DSP_IIR_BATCH_CASE(3);
+    case 4: DSP_IIR_BATCH_CASE(4);
+    case 5: DSP_IIR_BATCH_CASE(5);
+    case 6: DSP_IIR_BATCH_CASE(6);
+    case 7: DSP_IIR_BATCH_CASE(7);
+    case 8: DSP_IIR_BATCH_CASE(8);
+    case 9: case 10: DSP_IIR_BATCH_CASE(10);
+    case 11: case 12: DSP_IIR_BATCH_CASE(12);
+    case 13: case 14: case 15: case 16: DSP_IIR_BATCH_CASE(16);
+    case 17: case 18: case 19: case 20: DSP_IIR_BATCH_CASE(20);
+    default: return fail(DSP_GPU_EINVAL, "poles %d outside [1,20]", co.poles);
+    }
+#undef DSP_IIR_BATCH_CASE
 }
 
 int launch_iir_scan(const float *x, float *y, size_t channels, size_t n, const IirCoef &co, double *state,
                     hipStream_t s) {
     const bool al = is_aligned(x, y, n);
-    DSP_IIR_SWITCH(scan_dispatch)
+#define DSP_IIR_SCAN_CASE(P) \
+    return al ? scan_dispatch<P, true>(x, y, channels, n, co, state, s) : scan_dispatch<P, false>(x, y, channels, n, co, state, s)
+    switch (co.poles) {
+    case 1: DSP_IIR_SCAN_CASE(1);
+    case 2: DSP_IIR_SCAN_CASE(2);
+    case 3: DSP_IIR_SCAN_CASE(3);
+    case 4: DSP_IIR_SCAN_CASE(4);
+    case 5: DSP_IIR_SCAN_CASE(5);
+    case 6: DSP_IIR_SCAN_CASE(6);
+    case 7: DSP_IIR_SCAN_CASE(7);
+    case 8: DSP_IIR_SCAN_CASE(8);
+    default:  // P x P carry matrices in registers: beyond 8 poles the channel runs sequentially (BATCH)
+        return fail(DSP_GPU_EUNSUPPORTED, "IIR scan: poles %d > 8; use DSP_GPU_IIR_BATCH", co.poles);
+    }
+#undef DSP_IIR_SCAN_CASE
 }
 
 }  // namespace dspgpu

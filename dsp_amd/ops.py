@@ -167,6 +167,35 @@ def iir(x, a, b, c0: float = 1.0, d0: float = 0.0, state=None, mode: str = "auto
     return y
 
 
+def iir_multi(x, a, b, c0=None, d0=None, state=None, out=None):
+    """Filter bank: channel k runs its own Coefficients (a[k], b[k], c0[k], d0[k]); a, b [channels, poles+1]
+    float64, c0/d0 [channels] float64 or None (1 and 0), all living where x lives.  Block-wise form of a
+    retuned filter (eval/signals/wind_generator.h:150-167): call per block with new coefficients, carry `state`."""
+    x, px, mem = _prep(x, np.float32, "float32")
+    n = x.shape[-1]
+    channels = int(np.prod(x.shape[:-1])) if x.ndim > 1 else 1
+    poles = a.shape[-1] - 1
+
+    def chk(t, count, what):
+        if t is None:
+            return None
+        if _is_torch(t) != _is_torch(x):
+            raise capi.DspGpuError(capi.EINVAL, f"{what} must live where x lives")
+        ok = (t.is_contiguous() and t.dtype == torch.float64 and t.numel() == count) if _is_torch(t) \
+            else (t.flags.c_contiguous and t.dtype == np.float64 and t.size == count)
+        if not ok:
+            raise capi.DspGpuError(capi.EINVAL, f"{what} must be contiguous float64 with {count} entries")
+        return _ptr(t)
+
+    pa, pb = chk(a, channels * (poles + 1), "a"), chk(b, channels * (poles + 1), "b")
+    pc0, pd0 = chk(c0, channels, "c0"), chk(d0, channels, "d0")
+    pstate = chk(state, channels * 2 * poles, "state")
+    y = out if out is not None else _empty_like(x, tuple(x.shape), np.float32, "float32")
+    capi.check(capi.lib().dsp_gpu_iir_multi(px, _ptr(y), channels, n, pa, pb, poles, pc0, pd0, pstate, mem,
+                                            _stream_of(x)))
+    return y
+
+
 def fft_kernel_ms(x, out, inverse: bool, iters: int) -> float:
     """Average milliseconds per batched-FFT launch, timed with HIP events on x's stream."""
     n = x.shape[-1]

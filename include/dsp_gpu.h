@@ -123,7 +123,8 @@ int dsp_gpu_moving_average(const float *x, float *y, size_t channels, size_t n, 
  *     v[t] = sum_{i=0..poles} a[i] x[t-i] + sum_{i=1..poles} b[i] v[t-i]   (feedback ADDED)
  *     y[t] = v[t]*c0 + x[t]*d0
  * a, b: HOST pointers to poles+1 doubles (b[0] ignored), as produced by the designers in
- * recursive_filters.h.  1 <= poles <= 8.  Channel-major x[ch][n], y[ch][n].
+ * recursive_filters.h.  1 <= poles <= 20 (Coefficients<2..20>, recursive_filters.h:30-31); SCAN mode
+ * up to 8 poles (AUTO runs longer sections in BATCH).  Channel-major x[ch][n], y[ch][n].
  * Arithmetic and history are double, as in the reference (coefficients.h:9-12); samples are fp32.
  * `state` (may be NULL = start from rest, nothing written back) is [ch][2*poles] DOUBLES,
  * {x[t-1..t-poles], v[t-1..t-poles]} per channel, read before and written after the call:
@@ -134,6 +135,17 @@ int dsp_gpu_moving_average(const float *x, float *y, size_t channels, size_t n, 
 int dsp_gpu_iir(const float *x, float *y, size_t channels, size_t n, const double *a,
                 const double *b, int poles, double c0, double d0, double *state, int mode, int mem,
                 void *stream);
+
+/*
+ * The same recursion with ONE COEFFICIENT SET PER CHANNEL (a filter bank: every channel its own
+ * Coefficients<poles> object, e.g. a bank of band-pass filters tuned differently, the block-wise form of
+ * eval/signals/wind_generator.h:150-167, which retunes its band-pass as it runs).  a, b: [channels][poles+1]
+ * doubles (b[.][0] ignored), c0, d0: [channels] doubles or NULL (= 1 and 0, coefficients.h:11-12).  Unlike
+ * dsp_gpu_iir's shared a/b these arrays live where `mem` says, like `state` ([channels][2*poles], in/out,
+ * may be NULL).  One lane per channel (the BATCH kernel), 1 <= poles <= 8.
+ */
+int dsp_gpu_iir_multi(const float *x, float *y, size_t channels, size_t n, const double *a, const double *b,
+                      int poles, const double *c0, const double *d0, double *state, int mem, void *stream);
 
 /*
  * Local steps of the multi-GPU six-step FFT: one dsp::fft0 (fft.h:31-55) of N = N1*N2 points spread

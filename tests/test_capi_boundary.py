@@ -47,7 +47,9 @@ def test_argument_errors_without_a_gpu():
     assert L.dsp_gpu_convolve(p, p, 0, 8, p, 3, 0, 1, None) == capi.OK
     assert L.dsp_gpu_moving_average(p, p, 1, 4, 5, 1, None) == capi.EINVAL  # n < npoints
     assert L.dsp_gpu_iir(p, p, 1, 8, p, p, 0, 1.0, 0.0, None, 0, 1, None) == capi.EINVAL
-    assert L.dsp_gpu_iir(p, p, 1, 8, p, p, 9, 1.0, 0.0, None, 0, 1, None) == capi.EINVAL
+    assert L.dsp_gpu_iir(p, p, 1, 8, p, p, 21, 1.0, 0.0, None, 0, 1, None) == capi.EINVAL
+    assert L.dsp_gpu_iir_multi(p, p, 1, 8, p, p, 9, None, None, None, 1, None) == capi.EINVAL
+    assert L.dsp_gpu_iir_multi(p, p, 0, 8, p, p, 2, None, None, None, 1, None) == capi.OK
     with pytest.raises(capi.DspGpuError):
         capi.check(capi.EINVAL)
 

@@ -223,8 +223,97 @@ def test_errors(ops, dev):
     from dsp_amd import capi
     x = torch.zeros(2, 100, device=dev)
     with pytest.raises(capi.DspGpuError):
-        ops.iir(x, np.zeros(10), np.zeros(10))  # 9 poles
+        ops.iir(x, np.zeros(22), np.zeros(22))  # 21 poles
     with pytest.raises(capi.DspGpuError):
         ops.iir(x, np.zeros(3), np.zeros(3), state=torch.zeros(2, 4, device=dev))  # state must be float64
     with pytest.raises(capi.DspGpuError):
         ops.iir(x, np.array([1.0, np.nan, 0]), np.zeros(3))
+
+
+# ---- sections beyond 8 poles (Coefficients<10..20>, recursive_filters.h:30-31) ------------------------
+@pytest.mark.parametrize("poles,fc", [(10, 0.25), (12, 0.25), (16, 0.25), (20, None), (9, None), (13, None), (19, None)])
+def test_batch_high_order(ops, dev, orc, poles, fc):
+    """10..20-pole direct forms run one lane per channel; orders without a kernel of their own ride the next
+    one up with zero top coefficients.  Chebyshev designs at fc = 0.25, where the reference's own double
+    design is still well conditioned up to 16 poles (its 20-pole direct form diverges there, in the reference as
+    here); 20 poles and the odd orders are random stable sections."""
+    import torch
+    rng = np.random.default_rng(poles)
+    if fc is not None:
+        a, b = orc.chebyshev(fc, poles)
+    else:
+        a = rng.standard_normal(poles + 1) * 0.3
+        b = np.concatenate([[0.0], rng.uniform(-0.4, 0.4, poles) / poles])
+    channels, n = 70, 1500
+    x = rng.standard_normal((channels, n)).astype(np.float32)
+    st0 = rng.standard_normal((channels, 2 * poles)) * 0.1
+    st0[:, :poles] = st0[:, :poles].astype(np.float32)
+    so = np.zeros((channels, 2 * (poles + 1)))
+    so[:, 1:poles + 1] = st0[:, :poles]
+    so[:, poles + 2:] = st0[:, poles:]
+    want = orc.iir(x.astype(np.float64), a, b, state=so)
+    st = torch.from_numpy(st0.copy()).to(dev)
+    xd = torch.from_numpy(x).to(dev)
+    y = torch.cat([ops.iir(xd[:, :700].contiguous(), a, b, state=st, mode="batch"),
+                   ops.iir(xd[:, 700:].contiguous(), a, b, state=st, mode="batch")], dim=1)
+    assert rel_l2(y.cpu().numpy(), want) <= TOL
+    got_st = st.cpu().numpy()
+    assert np.allclose(got_st[:, :poles], so[:, 1:poles + 1])
+    assert np.allclose(got_st[:, poles:], so[:, poles + 2:], rtol=1e-4, atol=1e-6)
+    # AUTO takes the sequential kernel for these orders; SCAN says why it cannot
+    long = torch.from_numpy(rng.standard_normal((1, 70000)).astype(np.float32)).to(dev)
+    ya = ops.iir(long, a, b, mode="auto")
+    assert torch.equal(ya, ops.iir(long, a, b, mode="batch"))
+    from dsp_amd import capi
+    with pytest.raises(capi.DspGpuError) as e:
+        ops.iir(long, a, b, mode="scan")
+    assert e.value.code == capi.EUNSUPPORTED
+
+
+# ---- one coefficient set per channel (filter bank) ----------------------------------------------------
+@pytest.mark.parametrize("channels,n", [(1, 100), (67, 777), (300, 4096)])
+def test_iir_multi_filter_bank(ops, dev, orc, channels, n):
+    """Every channel its own band-pass / shelf (the block-wise form of the retuned filter of
+    eval/signals/wind_generator.h:150-167): each channel must equal the single-filter oracle run with its
+    coefficients; retuning between blocks carries the state like the reference's m_bp.a = bp.a assignment."""
+    import torch
+    from dsp_amd import design
+    rng = np.random.default_rng(channels + n)
+    x = rng.standard_normal((channels, n)).astype(np.float32)
+
+    def bank(seed):
+        r = np.random.default_rng(seed)
+        A, B, C0, D0 = [], [], [], []
+        for k in range(channels):
+            if k % 3 == 2:
+                a, b, c0, d0 = design.low_shelf(r.uniform(0.02, 0.2), r.uniform(-6, 6))
+            else:
+                a, b, c0, d0 = design.band_pass(r.uniform(0.02, 0.45), r.uniform(0.002, 0.02))
+            A.append(a); B.append(b); C0.append(c0); D0.append(d0)
+        return np.array(A), np.array(B), np.array(C0), np.array(D0)
+
+    A1, B1, C1, D1 = bank(1)
+    A2, B2, C2, D2 = bank(2)
+    cut = n // 3
+    want = np.zeros((channels, n))
+    for k in range(channels):
+        so = np.zeros(6)
+        want[k, :cut] = orc.iir(x[k, :cut].astype(np.float64), A1[k], B1[k], C1[k], D1[k], state=so)
+        want[k, cut:] = orc.iir(x[k, cut:].astype(np.float64), A2[k], B2[k], C2[k], D2[k], state=so)  # retuned, history kept
+    t = lambda v: torch.from_numpy(np.ascontiguousarray(v)).to(dev)
+    xd = t(x)
+    st = torch.zeros(channels, 4, dtype=torch.float64, device=dev)
+    y = torch.cat([ops.iir_multi(xd[:, :cut].contiguous(), t(A1), t(B1), t(C1), t(D1), state=st),
+                   ops.iir_multi(xd[:, cut:].contiguous(), t(A2), t(B2), t(C2), t(D2), state=st)], dim=1)
+    got = y.cpu().numpy()
+    for k in range(channels):
+        assert rel_l2(got[k], want[k]) <= TIGHT, k
+    # host pointers, default c0/d0 (= 1, 0): the band-pass channels only
+    sel = [k for k in range(channels) if k % 3 != 2]
+    sth = np.zeros((len(sel), 4))
+    yh = ops.iir_multi(np.ascontiguousarray(x[sel][:, :cut]), np.ascontiguousarray(A1[sel]), np.ascontiguousarray(B1[sel]), state=sth)
+    assert np.array_equal(yh, got[sel][:, :cut])
+    # uniform bank == the shared-coefficient entry point, bit for bit
+    a, b = orc.chebyshev(0.1, 4)
+    rep = lambda v: t(np.tile(v, (channels, 1)))
+    assert torch.equal(ops.iir_multi(xd, rep(a), rep(b)), ops.iir(xd, a, b, mode="batch"))
