@@ -42,8 +42,25 @@ __global__ __launch_bounds__(kThreads) void fft_lds_kernel(const void *__restric
     const size_t xf = tile * G + g;
     const bool live = xf < batch;
 
+    // Short transforms (T < 16 threads each): a thread's own points are only T*8 bytes apart from its
+    // neighbour's, so direct accesses would touch up to 64 lines per wave instruction.  The tile is contiguous
+    // in memory: move it with fully coalesced accesses and redistribute through the LDS image instead.
+    constexpr bool kStaged = T < 16;
+    const size_t tile_points = (batch - tile * G < static_cast<size_t>(G) ? batch - tile * G : static_cast<size_t>(G)) * N;
+
     c32 r[kPoints];
-    if (live) {
+    if constexpr (kStaged && !REAL_IN) {
+        const c32 *src = static_cast<const c32 *>(in_) + tile * kTile;
+#pragma unroll
+        for (int m = 0; m < kPoints; ++m) {
+            const int e = tid + kThreads * m;
+            lds[padded(e)] = static_cast<size_t>(e) < tile_points ? load_stream(src + e) : mk(0.0f, 0.0f);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < kPoints; ++m) r[m] = lds[padded(g * N + lt + T * m)];
+        __syncthreads();  // the passes reuse the image
+    } else if (live) {
         if constexpr (REAL_IN) {
             const float *src = static_cast<const float *>(in_) + xf * in_stride;
 #pragma unroll
@@ -63,7 +80,22 @@ __global__ __launch_bounds__(kThreads) void fft_lds_kernel(const void *__restric
 
     fft_passes<LOG2N, SIGN>(r, lds, lt, g * N);
 
-    if (live) {
+    if constexpr (kStaged) {
+        __syncthreads();  // the last pass's image has been read by everyone
+#pragma unroll
+        for (int m = 0; m < kPoints; ++m) {
+            int k = lt + T * m;
+            if constexpr (SHIFTED) k = (k + N / 2) & (N - 1);
+            lds[padded(g * N + k)] = r[m];
+        }
+        __syncthreads();
+        c32 *dst = out + tile * kTile;
+#pragma unroll
+        for (int m = 0; m < kPoints; ++m) {
+            const int e = tid + kThreads * m;
+            if (static_cast<size_t>(e) < tile_points) store_stream(dst + e, lds[padded(e)]);
+        }
+    } else if (live) {
         c32 *dst = out + xf * N;
 #pragma unroll
         for (int m = 0; m < kPoints; ++m) {
