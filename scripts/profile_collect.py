@@ -13,7 +13,8 @@ for w, key in KERNEL.items():
     d = os.path.join(SRC, w)
     if not os.path.isdir(d):
         continue
-    stats = glob.glob(os.path.join(d, "stats", "**", "*kernel_stats.csv"), recursive=True)
+    # gpurun merges new files into gpurun_out/ without deleting older runs: take the newest
+    stats = sorted(glob.glob(os.path.join(d, "stats", "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime, reverse=True)
     if stats:
         shutil.copy(stats[0], os.path.join(ROOT, "profiles", f"r01_{w}_kernel_stats.csv"))
         for r in csv.DictReader(open(stats[0])):
@@ -21,7 +22,7 @@ for w, key in KERNEL.items():
                 avg_ns = float(r["AverageNs"]); calls = int(r["Calls"])
     vals = {}
     for kind, cn in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
-        fs = glob.glob(os.path.join(d, kind, "**", "*counter_collection.csv"), recursive=True)
+        fs = sorted(glob.glob(os.path.join(d, kind, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime, reverse=True)[:1]
         v = [float(r["Counter_Value"]) for f in fs for r in csv.DictReader(open(f)) if key in r["Kernel_Name"] and r["Counter_Name"] == cn]
         if v:
             vals[cn] = sum(v) / len(v)
