@@ -84,11 +84,28 @@ DSP_DEV void run_row_partial(float *row, int count, double (&xh)[P], double (&vh
     }
 }
 
+// The same over a 16-byte aligned row, four samples per LDS access.
+template <int P, int LEN, bool STORE, typename C>
+DSP_DEV void run_row4(float *row, double (&xh)[P], double (&vh)[P], const C &co) {
+#pragma unroll
+    for (int i = 0; i < LEN; i += 4) {
+        float4 q = *reinterpret_cast<const float4 *>(row + i);
+        float *e = reinterpret_cast<float *>(&q);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const double x0 = static_cast<double>(e[k]);
+            const double v = iir_step<P>(x0, xh, vh, co);
+            if (STORE) e[k] = static_cast<float>(fma(v, co.c0, x0 * co.d0));
+        }
+        if (STORE) *reinterpret_cast<float4 *>(row + i) = q;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // batch: one lane per channel
 // ---------------------------------------------------------------------------------------------
 constexpr int kBt = 128;         // samples per tile row: 512-byte row segments (256-byte ones cap a plain copy at 4.4 TB/s, scripts/copy_patterns3.hip)
-constexpr int kBtPad = kBt + 1;  // conflict-free row walk
+constexpr int kBtPad = kBt + 4;  // rows 16-byte aligned; lane stride 132 dwords: 16-byte row walks are conflict-free
 constexpr int kBtIters = kBt * kWave / (kWave * 4);  // float4 loads per lane per tile = 16
 
 template <bool ALIGNED>
@@ -123,7 +140,7 @@ __global__ __launch_bounds__(kWave) void iir_batch_kernel(const float *__restric
                                                            size_t channels, size_t n, IirCoef uco,
                                                            double *__restrict__ state, size_t groups, size_t chunk,
                                                            int sp, IirPerChannel pc) {
-    __shared__ float tile[kWave * kBtPad];
+    __shared__ __attribute__((aligned(16))) float tile[kWave * kBtPad];
     constexpr int kLanesPerRow = kBt / 4;
     constexpr int kRowsPerIter = kWave / kLanesPerRow;
     const int lane = threadIdx.x;
@@ -159,17 +176,13 @@ __global__ __launch_bounds__(kWave) void iir_batch_kernel(const float *__restric
         const size_t t0 = tl * kBt;
 #pragma unroll
         for (int it = 0; it < kBtIters; ++it) {
-            float *dst = tile + (it * kRowsPerIter + lane / kLanesPerRow) * kBtPad + (lane % kLanesPerRow) * 4;
-            dst[0] = pre[it].x;
-            dst[1] = pre[it].y;
-            dst[2] = pre[it].z;
-            dst[3] = pre[it].w;
+            *reinterpret_cast<float4 *>(tile + (it * kRowsPerIter + lane / kLanesPerRow) * kBtPad + (lane % kLanesPerRow) * 4) = pre[it];
         }
         __syncthreads();
         if (tl + 1 < ntiles) batch_load<ALIGNED>(x, channels, n, ch0, t0 + kBt, lane, pre);
         if (live) {
             float *row = tile + lane * kBtPad;
-            if (t0 + kBt <= n) run_row<P, kBt, true>(row, xh, vh, co);
+            if (t0 + kBt <= n) run_row4<P, kBt, true>(row, xh, vh, co);
             else run_row_partial<P, true>(row, static_cast<int>(n - t0), xh, vh, co);
         }
         __syncthreads();
@@ -181,7 +194,8 @@ __global__ __launch_bounds__(kWave) void iir_batch_kernel(const float *__restric
             const float *src = tile + (it * kRowsPerIter + lane / kLanesPerRow) * kBtPad + (lane % kLanesPerRow) * 4;
             float *p = y + c * n + g;
             if (ALIGNED && g + 3 < n) {
-                store_stream_f4(p, src[0], src[1], src[2], src[3]);
+                const float4 q = *reinterpret_cast<const float4 *>(src);
+                store_stream_f4(p, q.x, q.y, q.z, q.w);
             } else {
                 p[0] = src[0];
                 if (g + 1 < n) p[1] = src[1];
@@ -204,12 +218,16 @@ __global__ __launch_bounds__(kWave) void iir_batch_kernel(const float *__restric
 // ---------------------------------------------------------------------------------------------
 // scan: block-parallel inside a channel
 // ---------------------------------------------------------------------------------------------
-constexpr int kSt = 256;            // threads = rows per tile
+constexpr int kSt = 64;             // threads = rows per tile: ONE WAVE per workgroup, so a tile needs no workgroup
+                                    // barrier, no cross-wave carry, and 16+ independent waves fit a CU (8.6 KB of LDS each)
 constexpr int kRow = 32;            // samples per row
-constexpr int kRowPad = kRow + 1;
-constexpr int kTile = kSt * kRow;   // 8192 samples per workgroup
-constexpr int kLevels = 8;          // log2(kSt)
-constexpr unsigned kScanWgsPerCu = 4; // resident workgroups per CU (34 KB of LDS each)
+constexpr int kRowPad = kRow + 4;    // 36 floats: rows stay 16-byte aligned and lanes walking their rows with 16-byte
+                                    // LDS accesses (lane stride 36 dwords) hit 16 disjoint 4-bank groups: conflict-free
+constexpr int kTile = kSt * kRow;   // 2048 samples per workgroup
+constexpr int kLevels = 6;          // log2(kSt)
+constexpr int kCt = 256;            // threads of the tile-carry kernel
+constexpr int kCtLevels = 8;        // log2(kCt)
+constexpr unsigned kScanWgsPerCu = 16; // resident workgroups (waves) per CU
 
 enum ScanMode { SCAN_REDUCE = 0, SCAN_APPLY = 1, SCAN_FUSED = 2 };
 
@@ -351,9 +369,7 @@ __global__ __launch_bounds__(kSt) void iir_scan_kernel(const float *__restrict__
                                                        const double *__restrict__ tile_c, unsigned ntiles, int warm,
                                                        int levels, const double *__restrict__ hrow) {
     constexpr int W = kWords<P, WIDE>;
-    constexpr int MS = W * P;
-    __shared__ float xs[(kSt + 1) * kRowPad];
-    __shared__ double sbuf[4 * W];  // wave aggregates
+    __shared__ __attribute__((aligned(16))) float xs[(kSt + 1) * kRowPad];
     const int tid = threadIdx.x;
     const size_t ch = blockIdx.y;
     const float *xc = x + ch * n;
@@ -400,11 +416,7 @@ __global__ __launch_bounds__(kSt) void iir_scan_kernel(const float *__restrict__
 #pragma unroll
     for (int q = 0; q < kPre; ++q) {
         const int u = tid * 4 + q * kSt * 4;
-        float *dst = xs + (u / kRow + 1) * kRowPad + (u % kRow);
-        dst[0] = pre[q].x;
-        dst[1] = pre[q].y;
-        dst[2] = pre[q].z;
-        dst[3] = pre[q].w;
+        *reinterpret_cast<float4 *>(xs + (u / kRow + 1) * kRowPad + (u % kRow)) = pre[q];
     }
     if (tid < P) {  // row "-1", column 31 - i holds x[start - 1 - i]
         float h = 0.0f;
@@ -431,8 +443,8 @@ __global__ __launch_bounds__(kSt) void iir_scan_kernel(const float *__restrict__
         xh[i] = xh0[i];
         vh[i] = 0.0;
     }
-    if (MODE == SCAN_REDUCE || last_row) run_row<P, kRow, false>(row, xh, vh, co);
-    else run_row<P, kRow, true>(row, xh, vh, co);
+    if (MODE == SCAN_REDUCE || last_row) run_row4<P, kRow, false>(row, xh, vh, co);
+    else run_row4<P, kRow, true>(row, xh, vh, co);
     SVec<P, WIDE> S;
     sv_zero<P, WIDE>(S);
 #pragma unroll
@@ -447,32 +459,12 @@ __global__ __launch_bounds__(kSt) void iir_scan_kernel(const float *__restrict__
         for (int i = 0; i < P; ++i) carry.hi[i] = sin_c[P + i];
     if (tid == 0) sv_mat_acc<P, WIDE>(S, mats, carry);
 
-    // phase B: inclusive scan of the row-end states, S_l = Z_l + A^32 S_{l-1}.  Inside a wave it is a
-    // Kogge-Stone scan over lanes with shuffles (no barrier); `levels` is the number of doubling levels
-    // whose matrix is not negligible (host: ||A^(32*2^j)|| > 2^-60), so a fast-decaying filter stops
-    // early.  Across the 4 waves: wave aggregates go through LDS once, the carry into wave w is
-    // c_w = agg_{w-1} + A^(32*64) c_{w-1}, and its effect on lane l, A^(32(l+1)) c_w, is the same scan
-    // applied to (A^32 c_w, 0, 0, ...).
-    const int lane = tid & 63, wave = tid >> 6;
-    const int wave_levels = levels < 6 ? levels : 6;
-    wave_scan<P, WIDE>(S, mats, wave_levels, lane);
-    if (lane == 63) sv_store<P, WIDE>(S, sbuf + wave * W);
-    __syncthreads();
-    SVec<P, WIDE> cw = carry;  // true state at the end of the previous wave (the tile carry for wave 0)
-    if (wave > 0) {
-        sv_zero<P, WIDE>(cw);
-        for (int w = 0; w < wave; ++w) {
-            SVec<P, WIDE> nxt;
-            sv_load<P, WIDE>(nxt, sbuf + w * W);
-            if (levels > 6) sv_mat_acc<P, WIDE>(nxt, mats + 6 * MS, cw);
-            cw = nxt;
-        }
-        SVec<P, WIDE> v;
-        sv_zero<P, WIDE>(v);
-        if (lane == 0) sv_mat_acc<P, WIDE>(v, mats, cw);
-        wave_scan<P, WIDE>(v, mats, wave_levels, lane);
-        sv_add<P, WIDE>(S, v);
-    }
+    // phase B: inclusive scan of the row-end states, S_l = Z_l + A^32 S_{l-1}: a Kogge-Stone scan over the
+    // lanes of the wave with shuffles.  `levels` is the number of doubling levels whose matrix is not
+    // negligible (host: ||A^(32*2^j)|| > 2^-60), so a fast-decaying filter stops early.
+    const int lane = tid;
+    wave_scan<P, WIDE>(S, mats, levels < kLevels ? levels : kLevels, lane);
+    const SVec<P, WIDE> cw = carry;  // true state at the start of the tile
     if (MODE == SCAN_REDUCE) {
         if (tid == kSt - 1) sv_store<P, WIDE>(S, tile_z + (ch * ntiles + tile) * W);
         continue;  // the barrier above ordered this tile's last LDS reads before the next tile's staging
@@ -504,11 +496,17 @@ __global__ __launch_bounds__(kSt) void iir_scan_kernel(const float *__restrict__
         // v[t] = v_zero_state[t] + sum_i hrow[t][i] * v[-1-i]: hrow[t] is the first row of A^(t+1) (host, from
         // the recursion run on unit states), uniform across lanes (scalar loads), no loop-carried dependency
 #pragma unroll
-        for (int t = 0; t < kRow; ++t) {
-            double corr = 0.0;
+        for (int t4 = 0; t4 < kRow; t4 += 4) {
+            float4 q = *reinterpret_cast<const float4 *>(row + t4);
+            float *e = reinterpret_cast<float *>(&q);
 #pragma unroll
-            for (int i = 0; i < P; ++i) corr = fma(hrow[t * P + i], vh[i], corr);
-            row[t] = static_cast<float>(fma(corr, co.c0, static_cast<double>(row[t])));
+            for (int k = 0; k < 4; ++k) {
+                double corr = 0.0;
+#pragma unroll
+                for (int i = 0; i < P; ++i) corr = fma(hrow[(t4 + k) * P + i], vh[i], corr);
+                e[k] = static_cast<float>(fma(corr, co.c0, static_cast<double>(e[k])));
+            }
+            *reinterpret_cast<float4 *>(row + t4) = q;
         }
     }
     __syncthreads();
@@ -518,7 +516,8 @@ __global__ __launch_bounds__(kSt) void iir_scan_kernel(const float *__restrict__
         if (g < out_begin || g >= n) continue;
         const float *src = xs + (u / kRow + 1) * kRowPad + (u % kRow);
         if (ALIGNED && g + 3 < n) {
-            store_stream_f4(yc + g, src[0], src[1], src[2], src[3]);
+            const float4 q = *reinterpret_cast<const float4 *>(src);
+            store_stream_f4(yc + g, q.x, q.y, q.z, q.w);
         } else {
             yc[g] = src[0];
             if (g + 1 < n) yc[g + 1] = src[1];
@@ -533,13 +532,13 @@ __global__ __launch_bounds__(kSt) void iir_scan_kernel(const float *__restrict__
 // Exclusive scan of the tile end states: C_0 = initial state, C_k = Z_{k-1} + MT C_{k-1}.
 // mats2: slot [0] = MT = A^8192, [1 + j] = MT^(G * 2^j); thread t owns tiles [t G, (t+1) G).
 template <int P, bool WIDE>
-__global__ __launch_bounds__(kSt) void iir_carry_kernel(const double *__restrict__ tile_z, double *__restrict__ tile_c,
+__global__ __launch_bounds__(kCt) void iir_carry_kernel(const double *__restrict__ tile_z, double *__restrict__ tile_c,
                                                          const double *__restrict__ mats2,
                                                          const double *__restrict__ state_in, unsigned ntiles,
                                                          unsigned G) {
     constexpr int W = kWords<P, WIDE>;
     constexpr int MS = W * P;
-    __shared__ double sbuf[W * kSt];
+    __shared__ double sbuf[W * kCt];
     const int tid = threadIdx.x;
     const size_t ch = blockIdx.x;
     const double *z = tile_z + ch * ntiles * W;
@@ -559,31 +558,31 @@ __global__ __launch_bounds__(kSt) void iir_carry_kernel(const double *__restrict
         s = nxt;
     }
 #pragma unroll 1
-    for (int j = 0; j < kLevels; ++j) {
+    for (int j = 0; j < kCtLevels; ++j) {
 #pragma unroll
-        for (int i = 0; i < W; ++i) sbuf[i * kSt + tid] = i < P ? s.hi[i] : s.lo[WIDE ? i - P : 0];
+        for (int i = 0; i < W; ++i) sbuf[i * kCt + tid] = i < P ? s.hi[i] : s.lo[WIDE ? i - P : 0];
         __syncthreads();
         const int off = 1 << j;
         if (tid >= off) {
             SVec<P, WIDE> o;
 #pragma unroll
             for (int i = 0; i < P; ++i) {
-                o.hi[i] = sbuf[i * kSt + tid - off];
-                if (WIDE) o.lo[i] = sbuf[(P + i) * kSt + tid - off];
+                o.hi[i] = sbuf[i * kCt + tid - off];
+                if (WIDE) o.lo[i] = sbuf[(P + i) * kCt + tid - off];
             }
             sv_mat_acc<P, WIDE>(s, mats2 + (1 + j) * MS, o);
         }
         __syncthreads();
     }
 #pragma unroll
-    for (int i = 0; i < W; ++i) sbuf[i * kSt + tid] = i < P ? s.hi[i] : s.lo[WIDE ? i - P : 0];
+    for (int i = 0; i < W; ++i) sbuf[i * kCt + tid] = i < P ? s.hi[i] : s.lo[WIDE ? i - P : 0];
     __syncthreads();
     s = first;
     if (tid > 0) {
 #pragma unroll
         for (int i = 0; i < P; ++i) {
-            s.hi[i] = sbuf[i * kSt + tid - 1];
-            if (WIDE) s.lo[i] = sbuf[(P + i) * kSt + tid - 1];
+            s.hi[i] = sbuf[i * kCt + tid - 1];
+            if (WIDE) s.lo[i] = sbuf[(P + i) * kCt + tid - 1];
         }
     }
     for (unsigned k = k0; k < k1; ++k) {
@@ -673,17 +672,17 @@ int scan_launch(const float *x, float *y, size_t channels, size_t n, const IirCo
     std::vector<double> table(static_cast<size_t>(9 + 9) * ms + hrow.size(), 0.0);  // 18 matrix slots, then hrow[32][P]
     std::copy(hrow.begin(), hrow.end(), table.begin() + 18 * ms);
     for (int j = 0; j <= kLevels; ++j) store_mat(table, j, pow32[j], P, WIDE);
-    const Mat &MT = pow32[kLevels];  // A^8192
+    const Mat &MT = pow32[kLevels];  // A^kTile
     const bool fused = warm > 0 || n <= static_cast<size_t>(kTile);
     if (warm < 0) warm = 0;
     unsigned ntiles;
     if (fused) ntiles = n <= static_cast<size_t>(kTile) ? 1u : 1u + static_cast<unsigned>((n - kTile + (kTile - warm) - 1) / (kTile - warm));
     else ntiles = static_cast<unsigned>((n + kTile - 1) / kTile);
-    const unsigned G = (ntiles + kSt - 1) / kSt;
+    const unsigned G = (ntiles + kCt - 1) / kCt;
     if (!fused) {
         store_mat(table, 9, MT, P, WIDE);
         Mat mg = mat_pow(MT, G, P);
-        for (int j = 0; j < kLevels; ++j) {
+        for (int j = 0; j < kCtLevels; ++j) {
             store_mat(table, 10 + j, mg, P, WIDE);
             mg = mat_mul(mg, mg, P);
         }
@@ -709,7 +708,7 @@ int scan_launch(const float *x, float *y, size_t channels, size_t n, const IirCo
     hipLaunchKernelGGL((iir_scan_kernel<P, SCAN_REDUCE, ALIGNED, WIDE>), grid, dim3(kSt), 0, s, x, y, n, co, d_table,
                        state_in, nullptr, tz, nullptr, ntiles, 0, levels, d_table + 18 * ms);
     if (int rc = check_launch("iir_scan_kernel<reduce>")) return rc;
-    hipLaunchKernelGGL((iir_carry_kernel<P, WIDE>), dim3(static_cast<unsigned>(channels)), dim3(kSt), 0, s, tz, tc,
+    hipLaunchKernelGGL((iir_carry_kernel<P, WIDE>), dim3(static_cast<unsigned>(channels)), dim3(kCt), 0, s, tz, tc,
                        d_table + 9 * ms, state_in, ntiles, G);
     if (int rc = check_launch("iir_carry_kernel")) return rc;
     hipLaunchKernelGGL((iir_scan_kernel<P, SCAN_APPLY, ALIGNED, WIDE>), grid, dim3(kSt), 0, s, x, y, n, co, d_table,
@@ -724,7 +723,7 @@ struct ScanPlan {
     std::vector<Mat> pow32;  // A^(32*2^j), j = 0..8
     std::vector<double> hrow;  // [32][P]: v[t] of the zero-input run started from the unit state e_i
     int levels = 0;          // doubling levels whose matrix still matters (norm > 2^-60)
-    int warm = -1;           // smallest multiple of 32 with ||A^W||_inf <= 2^-44 (<= kTile/8), else -1
+    int warm = -1;           // smallest multiple of 32 with ||A^W||_inf <= 2^-44 (<= kTile/4), else -1
     bool wide = false;       // carry states in double-double
     double predicted = 0.0;  // predicted relative error of the chosen carry arithmetic
     bool usable = false;
@@ -761,7 +760,7 @@ void build_plan(const IirCoef &co, ScanPlan &plan) {
             for (int c = 0; c < P; ++c) row += std::fabs(st[c * P + i].hi);
             if (!(row <= nrm)) nrm = row;
         }
-        if (plan.warm < 0 && k <= kTile / 8 && nrm <= 0x1p-44) plan.warm = k;
+        if (plan.warm < 0 && k <= kTile / 4 && nrm <= 0x1p-44) plan.warm = k;
         if (k == (kRow << next_level)) {
             Mat &m = plan.pow32[next_level];
             for (int i = 0; i < P; ++i)
