@@ -9,18 +9,20 @@
 //
 // Kernels
 //   iir_batch_kernel   one lane per channel (C4a).  A wave owns 64 channels and walks time in
-//                      tiles of 64 samples staged through a padded LDS tile, so HBM sees 256-byte
-//                      runs per channel while every lane reads its own row conflict-free; the next
-//                      tile's loads are in flight while the current one is computed.
+//                      tiles of 128 samples staged through a padded LDS tile, so HBM sees 512-byte
+//                      runs per channel while every lane walks its own 16-byte aligned row with
+//                      conflict-free 16-byte LDS accesses; the next tile's loads are in flight while
+//                      the current one is computed.  Also runs one coefficient set per lane.
 //   iir_scan_kernel    block-parallel linear-recurrence scan inside one channel (C4b).  A workgroup
-//                      owns a tile of 8192 contiguous samples = 256 rows of 32.  Phase A: every lane
-//                      runs its row from zero feedback state.  Phase B: Kogge-Stone scan over the
-//                      256 row-end states with the companion-matrix powers A^(32*2^j).  Phase C:
-//                      every lane re-runs its row from its true start state and writes y.
+//                      is ONE wave and owns a tile of 4096 contiguous samples = 64 rows of 64.
+//                      Phase A: every lane runs its row from zero feedback state and leaves the
+//                      zero-state outputs in LDS.  Phase B: Kogge-Stone scan over the 64 row-end states
+//                      with the companion-matrix powers A^(64*2^j), by wave shuffles.  Phase C: every
+//                      lane adds its true start state's contribution (a 64 x P table of A^(t+1) rows).
 //                      Across tiles either (REDUCE -> iir_carry_kernel -> APPLY: exact carries,
 //                      12 B/sample) or (FUSED: tiles overlap by W warm-up samples, chosen on the
 //                      host so that ||A^W|| <= 2^-44, i.e. the truncated history is below double
-//                      rounding; 8 B/sample * T/(T-W)).
+//                      rounding; 8 B/sample + 4 B * W/(T-W)).  Workgroups are persistent and prefetch.
 //   iir_carry_kernel   scan of the per-tile end states (one workgroup per channel).
 #include <cmath>
 #include <cstring>
@@ -220,10 +222,10 @@ __global__ __launch_bounds__(kWave) void iir_batch_kernel(const float *__restric
 // ---------------------------------------------------------------------------------------------
 constexpr int kSt = 64;             // threads = rows per tile: ONE WAVE per workgroup, so a tile needs no workgroup
                                     // barrier, no cross-wave carry, and 16+ independent waves fit a CU (8.6 KB of LDS each)
-constexpr int kRow = 32;            // samples per row
-constexpr int kRowPad = kRow + 4;    // 36 floats: rows stay 16-byte aligned and lanes walking their rows with 16-byte
-                                    // LDS accesses (lane stride 36 dwords) hit 16 disjoint 4-bank groups: conflict-free
-constexpr int kTile = kSt * kRow;   // 2048 samples per workgroup
+constexpr int kRow = 64;            // samples per row
+constexpr int kRowPad = kRow + 4;    // 68 floats: rows stay 16-byte aligned and lanes walking their rows with 16-byte
+                                    // LDS accesses (lane stride 68 = 4 mod 64 dwords) hit 16 disjoint 4-bank groups: conflict-free
+constexpr int kTile = kSt * kRow;   // 4096 samples per workgroup (measured: 32-sample rows 541, 64: 560, 128: 493 GSamples/s)
 constexpr int kLevels = 6;          // log2(kSt)
 constexpr int kCt = 256;            // threads of the tile-carry kernel
 constexpr int kCtLevels = 8;        // log2(kCt)
@@ -669,7 +671,7 @@ int scan_launch(const float *x, float *y, size_t channels, size_t n, const IirCo
                 hipStream_t s) {
     constexpr int W = kWords<P, WIDE>;
     const size_t ms = static_cast<size_t>(W) * P;
-    std::vector<double> table(static_cast<size_t>(9 + 9) * ms + hrow.size(), 0.0);  // 18 matrix slots, then hrow[32][P]
+    std::vector<double> table(static_cast<size_t>(9 + 9) * ms + hrow.size(), 0.0);  // 18 matrix slots, then hrow[kRow][P]
     std::copy(hrow.begin(), hrow.end(), table.begin() + 18 * ms);
     for (int j = 0; j <= kLevels; ++j) store_mat(table, j, pow32[j], P, WIDE);
     const Mat &MT = pow32[kLevels];  // A^kTile
@@ -721,7 +723,7 @@ int scan_launch(const float *x, float *y, size_t channels, size_t n, const IirCo
 struct ScanPlan {
     IirCoef co;
     std::vector<Mat> pow32;  // A^(32*2^j), j = 0..8
-    std::vector<double> hrow;  // [32][P]: v[t] of the zero-input run started from the unit state e_i
+    std::vector<double> hrow;  // [kRow][P]: v[t] of the zero-input run started from the unit state e_i
     int levels = 0;          // doubling levels whose matrix still matters (norm > 2^-60)
     int warm = -1;           // smallest multiple of 32 with ||A^W||_inf <= 2^-44 (<= kTile/4), else -1
     bool wide = false;       // carry states in double-double
