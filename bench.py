@@ -37,7 +37,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="fft",
-                    choices=["fft", "fir_direct", "fir_os", "iir_batch", "iir_scan", "mavg", "fft_dist"])
+                    choices=["fft", "fir_direct", "fir_direct_valu", "fir_os", "iir_batch", "iir_scan", "mavg", "fft_dist"])
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: every GPU gets the full per-GPU batch; strong: the one-GPU batch is channel-sharded")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -84,9 +84,10 @@ def make_fir(torch, dev, ops, rank, mode):
     def step():
         ops.convolve(x, taps, mode, out=y)
 
-    if mode == "direct":
+    if mode in ("direct", "direct_valu"):
         meta = dict(metric="fir_direct_throughput", unit="GMAC/s", dtype="f32", bound="mfma",
-                    alg_per_unit=2.0, alg_unit="flop/MAC", kernel="fir_direct_kernel")
+                    alg_per_unit=2.0, alg_unit="flop/MAC",
+                    kernel="fir_direct_kernel" if mode == "direct" else "fir_direct_valu_kernel (A/B partner, packed fp32 VALU)")
         units = channels * (n - (ntaps - 1)) * ntaps
     else:
         meta = dict(metric="fir_overlap_save_throughput", unit="GSamples/s", dtype="f32", bound="hbm",
@@ -189,13 +190,13 @@ def cpu_baseline(workload, seconds):
             lib.fft0(x)
             units += x.size
         unit, sample = "GSamples/s", "fft0 of 2^20 points in complex double (fft.h:31-55), repeated; 2^27+ does not fit a bounded CPU sample"
-    elif workload in ("fir_direct", "fir_os"):
+    elif workload in ("fir_direct", "fir_direct_valu", "fir_os"):
         h = sinc_taps_host(0.1, 511)
         x = rng.standard_normal(1 << 16).astype(np.float32)
         while time.perf_counter() < t_end:
             lib.fir(x, h)
-            units += (x.size - 510) * (511 if workload == "fir_direct" else 1)
-        unit = "GMAC/s" if workload == "fir_direct" else "GSamples/s"
+            units += (x.size - 510) * (511 if workload != "fir_os" else 1)
+        unit = "GMAC/s" if workload != "fir_os" else "GSamples/s"
         sample = f"SincFilter::apply (filter.h:123-140), float samples, 511 taps, repeated 2^16-sample slices of one channel"
     elif workload == "mavg":
         x = rng.standard_normal(1 << 22).astype(np.float32)
@@ -244,8 +245,9 @@ def main():
         step, units, meta = make_fft_dist(torch, dev, world, rank)
     elif args.workload == "fft":
         step, units, meta = make_fft(torch, dev, ops, rank)
-    elif args.workload in ("fir_direct", "fir_os"):
-        step, units, meta = make_fir(torch, dev, ops, rank, "direct" if args.workload == "fir_direct" else "overlap_save")
+    elif args.workload in ("fir_direct", "fir_direct_valu", "fir_os"):
+        step, units, meta = make_fir(torch, dev, ops, rank, {"fir_direct": "direct", "fir_direct_valu": "direct_valu",
+                                                             "fir_os": "overlap_save"}[args.workload])
     elif args.workload == "mavg":
         step, units, meta = make_mavg(torch, dev, ops, rank)
     else:

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libdsp_gpu.so")
 OK, EINVAL, EHIP, ENOMEM, EUNSUPPORTED = 0, -1, -2, -3, -4
 FORWARD, INVERSE = 0, 1
 MEM_HOST, MEM_DEVICE = 0, 1
-CONV_AUTO, CONV_DIRECT, CONV_OVERLAP_SAVE = 0, 1, 2
+CONV_AUTO, CONV_DIRECT, CONV_OVERLAP_SAVE, CONV_DIRECT_VALU = 0, 1, 2, 3
 IIR_AUTO, IIR_BATCH, IIR_SCAN = 0, 1, 2
 
 # every symbol include/dsp_gpu.h declares (tests check the library exports all of them)

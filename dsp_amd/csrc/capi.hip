@@ -242,8 +242,11 @@ static int convolve_impl(const char *who, const float *x, float *y, size_t chann
                          int ntaps, float *history, unsigned long long position, int mode, int mem, void *stream) {
     if (!x || !y || !taps) return fail(DSP_GPU_EINVAL, "%s: null buffer", who);
     if (ntaps < 1 || ntaps > 4096) return fail(DSP_GPU_EINVAL, "%s: ntaps %d outside [1,4096]", who, ntaps);
-    if (mode != DSP_GPU_CONV_AUTO && mode != DSP_GPU_CONV_DIRECT && mode != DSP_GPU_CONV_OVERLAP_SAVE)
+    if (mode != DSP_GPU_CONV_AUTO && mode != DSP_GPU_CONV_DIRECT && mode != DSP_GPU_CONV_OVERLAP_SAVE &&
+        mode != DSP_GPU_CONV_DIRECT_VALU)
         return fail(DSP_GPU_EINVAL, "%s: mode %d", who, mode);
+    if (mode == DSP_GPU_CONV_DIRECT_VALU && history)
+        return fail(DSP_GPU_EUNSUPPORTED, "%s: the VALU direct form has no streaming variant", who);
     if (mode == DSP_GPU_CONV_OVERLAP_SAVE && ntaps > 2049)
         return fail(DSP_GPU_EINVAL, "%s: overlap-save supports at most 2049 taps, got %d", who, ntaps);
     if (bad_mem(mem)) return fail(DSP_GPU_EINVAL, "%s: mem %d", who, mem);
@@ -277,7 +280,8 @@ static int convolve_impl(const char *who, const float *x, float *y, size_t chann
     const int zero_head = position >= order ? 0 : static_cast<int>(order - position);
     int rc = mode == DSP_GPU_CONV_OVERLAP_SAVE
                  ? launch_fir_overlap_save(dx, dy, channels, n, te->d_spectrum, ntaps, old_hist, zero_head, s)
-                 : launch_fir_direct(dx, dy, channels, n, te->d_taps, ntaps, old_hist, zero_head, s);
+             : mode == DSP_GPU_CONV_DIRECT_VALU ? launch_fir_direct_valu(dx, dy, channels, n, te->d_taps, ntaps, s)
+                                                : launch_fir_direct(dx, dy, channels, n, te->d_taps, ntaps, old_hist, zero_head, s);
     if (rc) return rc;
     if (history && hist_bytes) {  // new history = last ntaps-1 samples of (old history ++ x), via a scratch copy
         void *p = nullptr;

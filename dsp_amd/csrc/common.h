@@ -72,6 +72,8 @@ int launch_swap_axes(const float2 *in, float2 *out, size_t a, size_t b, size_t c
 int launch_transpose_blocks(const float2 *in, float2 *out, size_t blocks, size_t rows, size_t cols, hipStream_t s);
 int launch_fir_direct(const float *x, float *y, size_t channels, size_t n, const float *d_taps,
                       int ntaps, const float *hist, int zero_head, hipStream_t s);
+int launch_fir_direct_valu(const float *x, float *y, size_t channels, size_t n, const float *d_taps, int ntaps,
+                           hipStream_t s);
 int launch_fir_history(const float *x, size_t n, const float *old_hist, float *new_hist, size_t channels,
                        int ntaps, hipStream_t s);
 int launch_fir_overlap_save(const float *x, float *y, size_t channels, size_t n, const float2 *d_hspec,

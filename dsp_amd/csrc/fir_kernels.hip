@@ -147,6 +147,115 @@ __global__ __launch_bounds__(kFirThreads) void fir_direct_kernel(const float *__
 }
 
 // ---------------------------------------------------------------------------------------------
+// direct FIR on the vector ALU (the A/B partner of the MFMA kernel: BASELINE's north_star wants the matrix
+// cores used only if they beat the VALU formulation in rocprof; DSP_GPU_CONV_DIRECT_VALU selects this one)
+// ---------------------------------------------------------------------------------------------
+// A thread owns 16 consecutive outputs as 8 packed pairs and slides a 20-sample register window along the
+// taps, four taps per step: 32 v_pk_fma_f32 per 3 LDS reads.  v_pk_fma_f32 wants even-aligned register pairs,
+// but (x[q], x[q+1]) starts on an odd sample for every other tap, so the workgroup keeps TWO images of its
+// samples in LDS, xs0[u] = x[u] and xs1[u] = x[u+1], and odd taps read their pairs from the second one.
+// The window is a ring of five 4-sample groups; unrolling five steps makes every register index static.
+// Plain running fp32 sums (no segmentation): meant for filters up to ~1k taps.
+constexpr int kVfOut = 16;                       // outputs per thread
+constexpr int kVfTile = kThreads * kVfOut;       // 4096 outputs per workgroup
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+DSP_DEV int vf_pad(int u) { return u + ((u >> 4) << 2); }  // 4 pad floats per 16: 16-byte reads at lane stride 20 dwords
+
+__global__ __launch_bounds__(kThreads) void fir_direct_valu_kernel(const float *__restrict__ x, float *__restrict__ y,
+                                                                   size_t n, const float *__restrict__ taps, int ntaps,
+                                                                   int taps_p, int H) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int S = H + kVfTile;          // staged samples: logical u <-> sample tile0 - H + u
+    float *xs0 = smem;
+    float *xs1 = xs0 + vf_pad(S);
+    float *hp = xs1 + vf_pad(S);        // taps_p floats, zero padded
+    const int tid = threadIdx.x;
+    const size_t ch = blockIdx.y;
+    const long long nn = static_cast<long long>(n);
+    const long long tile0 = static_cast<long long>(blockIdx.x) * kVfTile;
+    const float *xc = x + ch * n;
+    float *yc = y + ch * n;
+
+    for (int u = tid * 4; u < S; u += kThreads * 4) {
+        const long long g = tile0 - H + u;
+        float4 v;
+        if (g >= 0 && g + 3 < nn && (n & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+            v = load_stream_f4(xc + g);
+        } else {
+            v.x = (g >= 0 && g < nn) ? xc[g] : 0.0f;
+            v.y = (g + 1 >= 0 && g + 1 < nn) ? xc[g + 1] : 0.0f;
+            v.z = (g + 2 >= 0 && g + 2 < nn) ? xc[g + 2] : 0.0f;
+            v.w = (g + 3 >= 0 && g + 3 < nn) ? xc[g + 3] : 0.0f;
+        }
+        *reinterpret_cast<float4 *>(xs0 + vf_pad(u)) = v;
+    }
+    for (int i = tid; i < taps_p; i += kThreads) hp[i] = i < ntaps ? taps[i] : 0.0f;
+    __syncthreads();
+    for (int u = tid * 4; u < S; u += kThreads * 4) {  // the image shifted by one sample
+        float4 v = *reinterpret_cast<const float4 *>(xs0 + vf_pad(u));
+        const float nxt = u + 4 < S ? xs0[vf_pad(u + 4)] : 0.0f;
+        *reinterpret_cast<float4 *>(xs1 + vf_pad(u)) = make_float4(v.y, v.z, v.w, nxt);
+    }
+    __syncthreads();
+
+    // ring of five groups (4 samples = 2 pairs each) per image; at step s the group at window position q
+    // (samples base - 4 + 4q .. +3) lives in slot (q - s + 5) % 5
+    v2f w0[10], w1[10], acc[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) acc[m] = v2f{0.0f, 0.0f};
+    int base = H + kVfOut * tid;  // logical index of this thread's first output; decreases by 4 per step
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+        const float4 a = *reinterpret_cast<const float4 *>(xs0 + vf_pad(base - 4 + 4 * q));
+        const float4 b = *reinterpret_cast<const float4 *>(xs1 + vf_pad(base - 4 + 4 * q));
+        w0[2 * q] = v2f{a.x, a.y};
+        w0[2 * q + 1] = v2f{a.z, a.w};
+        w1[2 * q] = v2f{b.x, b.y};
+        w1[2 * q + 1] = v2f{b.z, b.w};
+    }
+    for (int c0 = 0; c0 < taps_p; c0 += 20) {
+#pragma unroll
+        for (int s = 0; s < 5; ++s) {
+            const float4 h = *reinterpret_cast<const float4 *>(hp + c0 + 4 * s);  // uniform address: broadcast
+            // next step's lowest group, into the slot of this step's highest one (position 4)
+            const int nb = base - 8;
+            const float4 na = *reinterpret_cast<const float4 *>(xs0 + vf_pad(nb));
+            const float4 nbv = *reinterpret_cast<const float4 *>(xs1 + vf_pad(nb));
+            const float hk[4] = {h.x, h.y, h.z, h.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const v2f hh = v2f{hk[k], hk[k]};
+#pragma unroll
+                for (int m = 0; m < 8; ++m) {
+                    // even tap: pair (x[base+2m-k], +1) from image 0; odd tap: the same pair starts on an odd
+                    // sample = aligned pair (base+2m-k-1) of image 1
+                    const int d = (k & 1) ? 2 * m - k - 1 : 2 * m - k;  // even, in [-4, 14]
+                    const int P = (d + 4) / 2, q = P / 2, half = P % 2;
+                    const int slot = (q - s + 5) % 5;
+                    const v2f pr = (k & 1) ? w1[2 * slot + half] : w0[2 * slot + half];
+                    acc[m] = __builtin_elementwise_fma(hh, pr, acc[m]);
+                }
+            }
+            const int hs = (4 - s + 5) % 5;  // slot of the highest group of this step
+            w0[2 * hs] = v2f{na.x, na.y};
+            w0[2 * hs + 1] = v2f{na.z, na.w};
+            w1[2 * hs] = v2f{nbv.x, nbv.y};
+            w1[2 * hs + 1] = v2f{nbv.z, nbv.w};
+            base -= 4;
+        }
+    }
+    const long long j0 = tile0 + kVfOut * tid;
+    const long long order = ntaps - 1;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const long long j = j0 + 2 * m;
+        if (j < nn) yc[j] = j >= order ? acc[m].x : 0.0f;  // filter.h:133: first M outputs stay 0
+        if (j + 1 < nn) yc[j + 1] = j + 1 >= order ? acc[m].y : 0.0f;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // overlap-save FIR
 // ---------------------------------------------------------------------------------------------
 constexpr int kOsN = 4096;
@@ -383,6 +492,20 @@ int launch_fir_history(const float *x, size_t n, const float *old_hist, float *n
     const unsigned grid = static_cast<unsigned>(std::min<size_t>((channels * hlen + kThreads - 1) / kThreads, 65536));
     hipLaunchKernelGGL(fir_history_kernel, dim3(grid), dim3(kThreads), 0, s, x, n, old_hist, new_hist, channels, hlen);
     return check_launch("fir_history_kernel");
+}
+
+int launch_fir_direct_valu(const float *x, float *y, size_t channels, size_t n, const float *d_taps, int ntaps,
+                           hipStream_t s) {
+    if (ntaps > 1024) return fail(DSP_GPU_EUNSUPPORTED, "direct FIR (VALU): at most 1024 taps, got %d", ntaps);
+    if (channels > 65535) return fail(DSP_GPU_EUNSUPPORTED, "direct FIR: more than 65535 channels per call");
+    const int taps_p = ((ntaps + 19) / 20) * 20;
+    const int H = ((taps_p + 8 + 15) / 16) * 16;  // staged history: the window reaches base - 8 on its last prefetch
+    const int S = H + kVfTile;
+    const size_t lds_bytes = (2 * static_cast<size_t>(S + (S / 16) * 4 + 8) + taps_p) * sizeof(float);
+    const size_t blocks = (n + kVfTile - 1) / kVfTile;
+    hipLaunchKernelGGL(fir_direct_valu_kernel, dim3(static_cast<unsigned>(blocks), static_cast<unsigned>(channels)),
+                       dim3(kThreads), lds_bytes, s, x, y, n, d_taps, ntaps, taps_p, H);
+    return check_launch("fir_direct_valu_kernel");
 }
 
 int launch_fir_direct(const float *x, float *y, size_t channels, size_t n, const float *d_taps, int ntaps,

@@ -88,7 +88,8 @@ def fft(x, nf: int, inverse: bool = False, shift: bool = False):
 
 
 _MODES = {"auto": capi.CONV_AUTO, "direct": capi.CONV_DIRECT, "time": capi.CONV_DIRECT,
-          "overlap_save": capi.CONV_OVERLAP_SAVE, "frequency": capi.CONV_OVERLAP_SAVE}
+          "overlap_save": capi.CONV_OVERLAP_SAVE, "frequency": capi.CONV_OVERLAP_SAVE,
+          "direct_valu": capi.CONV_DIRECT_VALU}
 
 
 def convolve(x, taps, mode: str = "auto", out=None):

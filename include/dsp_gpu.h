@@ -52,6 +52,8 @@ extern "C" {
 #define DSP_GPU_CONV_AUTO         0
 #define DSP_GPU_CONV_DIRECT       1
 #define DSP_GPU_CONV_OVERLAP_SAVE 2
+#define DSP_GPU_CONV_DIRECT_VALU  3 /* direct form on the vector ALU instead of the matrix cores: the A/B partner
+                                      kept for measurement (one-shot calls, <= 1024 taps); AUTO never picks it */
 
 /* IIR execution mode */
 #define DSP_GPU_IIR_AUTO  0

@@ -213,3 +213,21 @@ def test_streaming_equals_one_shot(ops, dev, orc, mode, tol, ntaps, chunks):
         outs.append(ops.convolve_stream(np.ascontiguousarray(x[:, pos:pos + c]), h, hh, pos, mode=mode))
         pos += c
     assert np.array_equal(np.concatenate(outs, axis=1), got)
+
+
+# ---- the VALU direct form kept as the matrix-core kernel's A/B partner ---------------------------------
+@pytest.mark.parametrize("ntaps,channels,n", [(511, 3, 20000), (1, 2, 100), (20, 1, 4096), (33, 5, 4097), (1024, 2, 9000), (101, 2, 50)])
+def test_direct_valu_matches(ops, dev, orc, ntaps, channels, n):
+    """Same results as the MFMA kernel to the direct-FIR tolerance (north_star: <= 1e-6 against the reference)."""
+    import torch
+    rng = np.random.default_rng(ntaps * 7 + n)
+    h = orc.sinc(0.15, ntaps)[:ntaps] if ntaps > 1 else np.array([1.25])
+    x = rng.standard_normal((channels, n)).astype(np.float32)
+    want = orc.fir(x.astype(np.float64), h)
+    guard = torch.full((channels + 2, n), 7.0, device=dev)
+    ops.convolve(torch.from_numpy(x).to(dev), h, mode="direct_valu", out=guard[1:-1])
+    g = guard.cpu().numpy()
+    assert (g[0] == 7).all() and (g[-1] == 7).all()
+    assert rel_l2(g[1:-1], want) <= DIRECT_TOL
+    assert not g[1:-1][:, : min(n, ntaps - 1)].any()
+    assert rel_l2(ops.convolve(x, h, mode="direct_valu"), want) <= DIRECT_TOL  # host pointers
