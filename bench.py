@@ -42,6 +42,8 @@ def parse():
                     help="weak: every GPU gets the full per-GPU batch; strong: the one-GPU batch is channel-sharded")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the CPU baseline sample")
+    ap.add_argument("--cpu-threads", type=int, default=int(os.environ.get("OMP_NUM_THREADS", "0") or 0),
+                    help="also time the reference on this many host threads (0/1: skip); default $OMP_NUM_THREADS")
     return ap.parse_args()
 
 
@@ -168,53 +170,65 @@ def cheby_lp4_host():
 
 
 # ----------------------------------------------------------------------------------------------
-def cpu_baseline(workload, seconds):
-    """Time the reference's CPU code on a bounded sample of the same workload (rank 0, N=1)."""
+def cpu_baseline(workload, seconds, threads=1):
+    """Time the reference's CPU code on a bounded sample of the same workload (rank 0, N=1).
+    threads > 1: the same per-channel function on `threads` host threads at once, each on its own slice (the
+    "parallel for over channels around the unchanged function" of SURVEY.md 8d; ctypes drops the GIL in the call)."""
+    if threads > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(threads) as pool:
+            parts = list(pool.map(lambda k: _cpu_sample(workload, seconds, 1234 + k), range(threads)))
+        dt = time.perf_counter() - t0
+        out = dict(parts[0])
+        out.update(value=sum(p["units"] for p in parts) / dt / 1e9, cores=threads, seconds=round(dt, 2))
+        out.pop("units")
+        return out
+    out = _cpu_sample(workload, seconds, 1234)
+    out.pop("units")
+    return out
+
+
+def _cpu_sample(workload, seconds, seed):
     from oracle import available, load
     kind = "reference" if available("ref") else "port"
     lib = load("ref" if kind == "reference" else "fast")
-    rng = np.random.default_rng(1234)
-    t_end = time.perf_counter() + seconds
-    units = 0
-    t0 = time.perf_counter()
+    rng = np.random.default_rng(seed)
     if workload == "fft":
-        chunk = 256
-        x = (rng.standard_normal((chunk, 4096)) + 1j * rng.standard_normal((chunk, 4096)))
-        while time.perf_counter() < t_end:
-            lib.fft0(x)
-            units += chunk * 4096
-        unit, sample = "GSamples/s", f"{units // 4096} of 65,536 transforms, fft0 in complex double as the reference computes (fft.h:31-55)"
+        x = (rng.standard_normal((256, 4096)) + 1j * rng.standard_normal((256, 4096)))
+        call, per_call, unit = (lambda: lib.fft0(x)), x.size, "GSamples/s"
+        sample = "{calls} x 256 of 65,536 transforms, fft0 in complex double as the reference computes (fft.h:31-55)"
     elif workload == "fft_dist":
         x = (rng.standard_normal(1 << 20) + 1j * rng.standard_normal(1 << 20))
-        while time.perf_counter() < t_end:
-            lib.fft0(x)
-            units += x.size
-        unit, sample = "GSamples/s", "fft0 of 2^20 points in complex double (fft.h:31-55), repeated; 2^27+ does not fit a bounded CPU sample"
+        call, per_call, unit = (lambda: lib.fft0(x)), x.size, "GSamples/s"
+        sample = "fft0 of 2^20 points in complex double (fft.h:31-55), {calls} times; 2^27+ does not fit a bounded CPU sample"
     elif workload in ("fir_direct", "fir_direct_valu", "fir_os"):
         h = sinc_taps_host(0.1, 511)
         x = rng.standard_normal(1 << 16).astype(np.float32)
-        while time.perf_counter() < t_end:
-            lib.fir(x, h)
-            units += (x.size - 510) * (511 if workload != "fir_os" else 1)
+        call = lambda: lib.fir(x, h)
+        per_call = (x.size - 510) * (511 if workload != "fir_os" else 1)
         unit = "GMAC/s" if workload != "fir_os" else "GSamples/s"
-        sample = f"SincFilter::apply (filter.h:123-140), float samples, 511 taps, repeated 2^16-sample slices of one channel"
+        sample = "SincFilter::apply (filter.h:123-140), float samples, 511 taps, {calls} 2^16-sample slices of one channel"
     elif workload == "mavg":
         x = rng.standard_normal(1 << 22).astype(np.float32)
-        while time.perf_counter() < t_end:
-            lib.moving_average(x, 511)
-            units += x.size
-        unit, sample = "GSamples/s", "MovingAverageFilter{511} (filter.h:81-101), float, repeated 2^22-sample slices"
+        call, per_call, unit = (lambda: lib.moving_average(x, 511)), x.size, "GSamples/s"
+        sample = "MovingAverageFilter{{511}} (filter.h:81-101), float, {calls} 2^22-sample slices"
     else:
-        from dsp_amd import design
-        a, b = design.chebyshev(0.1, 4)
+        a, b = cheby_lp4_host()
         x = rng.standard_normal(1 << 22).astype(np.float32)
-        while time.perf_counter() < t_end:
-            lib.iir(x, a, b)
-            units += x.size
-        unit, sample = "GSamples/s", "Coefficients<4>::operator()(SampleBuffer) (coefficients.h:88-130), float, repeated 2^22-sample slices"
+        call, per_call, unit = (lambda: lib.iir(x, a, b)), x.size, "GSamples/s"
+        sample = "Coefficients<4>::operator()(SampleBuffer) (coefficients.h:88-130), float, {calls} 2^22-sample slices"
+    calls = 0
+    t0 = time.perf_counter()
+    while True:  # at least one call, then until the budget is spent
+        call()
+        calls += 1
+        if time.perf_counter() - t0 >= seconds:
+            break
     dt = time.perf_counter() - t0
-    return {"value": units / dt / 1e9, "unit": unit, "cores": 1, "kind": kind, "sample": sample,
-            "seconds": round(dt, 2)}
+    units = calls * per_call
+    return {"value": units / dt / 1e9, "unit": unit, "cores": 1, "kind": kind, "sample": sample.format(calls=calls),
+            "seconds": round(dt, 2), "units": units}
 
 
 def main():
@@ -300,6 +314,8 @@ def main():
                 "config": meta["config"], "roofline": roof}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_seconds)
+            if args.cpu_threads > 1:  # reported beside it, never the target (the roofline fraction is)
+                line["cpu_baseline_all_cores"] = cpu_baseline(args.workload, args.cpu_seconds / 2, args.cpu_threads)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -68,10 +68,9 @@ class OracleLib:
         log2n = int(n).bit_length() - 1
         assert 1 << log2n == n
         out = np.empty_like(x)
-        fn = self._fn("fft0")
         xi, oi = x.reshape(-1, n), out.reshape(-1, n)
-        for r in range(xi.shape[0]):
-            fn(_d(xi[r].view(np.float64)), _d(oi[r].view(np.float64)), C.c_int(log2n), C.c_int(int(inverse)))
+        self._fn("fft0_batch")(_d(xi.view(np.float64)), _d(oi.view(np.float64)), C.c_int(log2n), C.c_int(int(inverse)),
+                               C.c_size_t(xi.shape[0]))
         return out
 
     def fft0_f32(self, x, inverse=False):

@@ -32,6 +32,7 @@ extern "C" {
 /* fft.h:31-55  out-of-place radix-2 DIT, complex double interleaved (re,im).
  * inverse=0 -> FFTType::FORWARD (twiddle e^{+i pi/m2}), 1 -> INVERSE. Unnormalised. */
 void ORC_NAME(fft0)(const double *in, double *out, int log2n, int inverse);
+void ORC_NAME(fft0_batch)(const double *in, double *out, int log2n, int inverse, size_t batch);
 /* same algorithm instantiated in float (NOT in the reference; like-for-like CPU baseline) */
 void ORC_NAME(fft0_f32)(const float *in, float *out, int log2n, int inverse);
 /* fft.h:57-83  real input wrapper: pads n_in samples to 2^ceil(log2 nf); returns padded size */

@@ -156,6 +156,11 @@ void ref_fft0(const double *in, double *out, int log2n, int inverse) {
     else dsp::fft0<dsp::FFTType::FORWARD>(ci, co, log2n);
 }
 
+void ref_fft0_batch(const double *in, double *out, int log2n, int inverse, size_t batch) {
+    const size_t stride = static_cast<size_t>(2) << log2n;
+    for (size_t b = 0; b < batch; ++b) ref_fft0(in + b * stride, out + b * stride, log2n, inverse);
+}
+
 // The reference has no float FFT: ref_fft0_f32 is deliberately not defined.
 
 int ref_fft_real(const double *td, size_t n_in, double *out, int nf, int inverse) {
