@@ -157,13 +157,15 @@ DSP_DEV void column_exchange(c32 (&r)[kPoints], c32 *lds, int lt, int c) {
     for (int m = 0; m < kPoints; ++m) r[m] = lds[(lt + T * m) * C + c];
 }
 
-template <int LOG2L, int SIGN>
-__global__ __launch_bounds__(kThreads) void fft_column_kernel(const c32 *__restrict__ in, c32 *__restrict__ out,
-                                                              ColumnPlan plan, size_t columns_per_a) {
+// TH threads per workgroup: 256, or 512 for the long columns so that a workgroup still covers 32-64 adjacent
+// columns (256-512 contiguous bytes per access; with 128-256 the pass ran at 4.4 TB/s against 5.8 for rows).
+template <int LOG2L, int SIGN, int TH>
+__global__ __launch_bounds__(TH) void fft_column_kernel(const c32 *__restrict__ in, c32 *__restrict__ out,
+                                                        ColumnPlan plan, size_t columns_per_a) {
     constexpr int L = 1 << LOG2L;
     constexpr int T = L / kPoints;   // threads per column
-    constexpr int C = kThreads / T;  // columns per workgroup
-    __shared__ c32 lds[kTile];
+    constexpr int C = TH / T;        // columns per workgroup
+    __shared__ c32 lds[TH * kPoints + TH];  // + one pad element per column for the transposed store
 
     const int tid = threadIdx.x;
     const int c = tid % C;
@@ -186,16 +188,42 @@ __global__ __launch_bounds__(kThreads) void fft_column_kernel(const c32 *__restr
     }
 
     const size_t bhi = b / plan.Bi, blo = b % plan.Bi;
+    if (plan.tw_log2 > 0) {
+        // W^(k*bhi), k = lt + T*m:  W^(lt*bhi) * (W^(T*bhi))^m -- two sincos and a product tree (depth 4) instead
+        // of sixteen sincos, which cost more VALU work than the transform itself
+        const unsigned mask = (1u << plan.tw_log2) - 1u;
+        const unsigned ub = static_cast<unsigned>(bhi);
+        const c32 w0 = unit_root<SIGN>((static_cast<unsigned>(lt) * ub) & mask, plan.tw_log2);
+        c32 pw[kPoints];
+        pw[1] = unit_root<SIGN>((static_cast<unsigned>(T) * ub) & mask, plan.tw_log2);
+#pragma unroll
+        for (int m = 2; m < kPoints; ++m) pw[m] = cmul(pw[m >> 1], pw[m - (m >> 1)]);
+        r[0] = cmul(r[0], w0);
+#pragma unroll
+        for (int m = 1; m < kPoints; ++m) r[m] = cmul(r[m], cmul(w0, pw[m]));
+    }
+    if (plan.s_k == 1 && plan.Bi == 1) {
+        // transposed store (k contiguous per column): stage the tile as [column][k] so that a wave writes 512
+        // contiguous bytes of one column per instruction instead of 4 elements of each of 16 columns
+        __syncthreads();  // the last exchange's image has been read by everyone
+#pragma unroll
+        for (int m = 0; m < kPoints; ++m) lds[c * (L + 1) + lt + T * m] = r[m];
+        __syncthreads();
+        const size_t b0 = (tile % tiles_per_a) * C;
+        c32 *base = out + a * L * plan.B + b0 * plan.s_hi;
+#pragma unroll
+        for (int m = 0; m < kPoints; ++m) {
+            const int i = tid + TH * m;
+            const int cc = i / L, k = i % L;
+            store_stream(base + static_cast<size_t>(cc) * plan.s_hi + k, lds[cc * (L + 1) + k]);
+        }
+        return;
+    }
     c32 *dst = out + a * L * plan.B + bhi * plan.s_hi + blo;
 #pragma unroll
     for (int m = 0; m < kPoints; ++m) {
         const unsigned k = lt + T * m;
-        c32 v = r[m];
-        if (plan.tw_log2 > 0) {
-            const unsigned e = (k * static_cast<unsigned>(bhi)) & ((1u << plan.tw_log2) - 1u);
-            v = cmul(v, unit_root<SIGN>(e, plan.tw_log2));
-        }
-        dst[static_cast<size_t>(k) * plan.s_k] = v;
+        dst[static_cast<size_t>(k) * plan.s_k] = r[m];
     }
 }
 
@@ -267,19 +295,24 @@ int dispatch_small(int log2n, const void *in, c32 *out, size_t batch, size_t n_i
 int launch_column(int log2l, const c32 *in, c32 *out, const ColumnPlan &plan, size_t slabs, int direction,
                   hipStream_t s) {
     const int L = 1 << log2l;
-    const int C = kTile / L;
+    const bool wide = log2l >= 7 && plan.B % (2 * kTile / L) == 0;  // 512 threads: twice the columns
+    const int C = (wide ? 2 : 1) * kTile / L;
     if (plan.B % C != 0) return fail(DSP_GPU_EINVAL, "column pass: inner extent %zu not a multiple of %d", plan.B, C);
     const size_t blocks = slabs * (plan.B / C);
     switch (log2l) {
-#define DSP_CASE(K)                                                                                              \
-    case K:                                                                                                      \
+#define DSP_LAUNCH(K, TH)                                                                                          \
         if (direction == DSP_GPU_FORWARD)                                                                        \
-            hipLaunchKernelGGL((fft_column_kernel<K, +1>), dim3(blocks), dim3(kThreads), 0, s, in, out, plan, plan.B); \
+            hipLaunchKernelGGL((fft_column_kernel<K, +1, TH>), dim3(blocks), dim3(TH), 0, s, in, out, plan, plan.B); \
         else                                                                                                     \
-            hipLaunchKernelGGL((fft_column_kernel<K, -1>), dim3(blocks), dim3(kThreads), 0, s, in, out, plan, plan.B); \
-        break;
-        DSP_CASE(4) DSP_CASE(5) DSP_CASE(6) DSP_CASE(7) DSP_CASE(8)
+            hipLaunchKernelGGL((fft_column_kernel<K, -1, TH>), dim3(blocks), dim3(TH), 0, s, in, out, plan, plan.B);
+#define DSP_CASE(K) \
+    case K: DSP_LAUNCH(K, kThreads) break;
+#define DSP_CASE_WIDE(K) \
+    case K: if (wide) { DSP_LAUNCH(K, 2 * kThreads) } else { DSP_LAUNCH(K, kThreads) } break;
+        DSP_CASE(4) DSP_CASE(5) DSP_CASE(6) DSP_CASE_WIDE(7) DSP_CASE_WIDE(8)
 #undef DSP_CASE
+#undef DSP_CASE_WIDE
+#undef DSP_LAUNCH
     default: return fail(DSP_GPU_EINVAL, "column pass length 2^%d unsupported", log2l);
     }
     return check_launch("fft_column_kernel");
