@@ -35,6 +35,7 @@ EXPORTS = (
     "dsp_gpu_fft_columns",
     "dsp_gpu_swap_axes",
     "dsp_gpu_transpose_blocks",
+    "dsp_gpu_fft_rows_exchange",
 )
 
 
@@ -68,7 +69,8 @@ def lib() -> C.CDLL:
         L.dsp_gpu_fft_columns.argtypes = [vp, vp, i, sz, i, vp]
         L.dsp_gpu_swap_axes.argtypes = [vp, vp, sz, sz, sz, i, sz, i, vp]
         L.dsp_gpu_transpose_blocks.argtypes = [vp, vp, sz, sz, sz, vp]
-        for name in ("dsp_gpu_fft_columns", "dsp_gpu_swap_axes", "dsp_gpu_transpose_blocks"):
+        L.dsp_gpu_fft_rows_exchange.argtypes = [vp, vp, i, sz, sz, i, sz, i, vp]
+        for name in ("dsp_gpu_fft_columns", "dsp_gpu_swap_axes", "dsp_gpu_transpose_blocks", "dsp_gpu_fft_rows_exchange"):
             getattr(L, name).restype = i
         for name in ("dsp_gpu_fft_batch", "dsp_gpu_fft_batch_timed", "dsp_gpu_fft_real_batch", "dsp_gpu_convolve",
                      "dsp_gpu_moving_average", "dsp_gpu_iir", "dsp_gpu_device_count", "dsp_gpu_shutdown"):

@@ -445,6 +445,18 @@ int dsp_gpu_swap_axes(const void *in, void *out, size_t a, size_t b, size_t c, i
                             direction, static_cast<hipStream_t>(stream));
 }
 
+int dsp_gpu_fft_rows_exchange(const void *in, void *out, int log2n2, size_t rows, size_t world, int tw_log2n,
+                              size_t tw_row0, int direction, void *stream) {
+    if (!in || !out || in == out) return fail(DSP_GPU_EINVAL, "dsp_gpu_fft_rows_exchange: null or aliased buffer");
+    if (log2n2 < 1 || log2n2 > 24 || tw_log2n < log2n2 || tw_log2n > 40)
+        return fail(DSP_GPU_EINVAL, "dsp_gpu_fft_rows_exchange: log2n2 %d, tw_log2n %d", log2n2, tw_log2n);
+    if (direction != DSP_GPU_FORWARD && direction != DSP_GPU_INVERSE)
+        return fail(DSP_GPU_EINVAL, "dsp_gpu_fft_rows_exchange: direction %d", direction);
+    if (rows == 0) return DSP_GPU_OK;
+    return launch_fft_rows_exchange(static_cast<const float2 *>(in), static_cast<float2 *>(out), log2n2, rows, world,
+                                    tw_log2n, tw_row0, direction, static_cast<hipStream_t>(stream));
+}
+
 int dsp_gpu_transpose_blocks(const void *in, void *out, size_t blocks, size_t rows, size_t cols, void *stream) {
     if (!in || !out || in == out) return fail(DSP_GPU_EINVAL, "dsp_gpu_transpose_blocks: null or aliased buffer");
     return launch_transpose_blocks(static_cast<const float2 *>(in), static_cast<float2 *>(out), blocks, rows, cols,

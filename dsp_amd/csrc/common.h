@@ -67,6 +67,8 @@ int launch_fft_batch(const float2 *in, float2 *out, int log2n, size_t batch, int
 int launch_fft_real_batch(const float *in, size_t n_in, size_t in_stride, float2 *out, int log2n,
                           size_t batch, int direction, int shifted, hipStream_t s);
 int launch_fft_columns(const float2 *in, float2 *out, int log2n, size_t cols, int direction, hipStream_t s);
+int launch_fft_rows_exchange(const float2 *in, float2 *out, int log2n2, size_t rows, size_t world, int tw_log2n,
+                             unsigned long long row0, int direction, hipStream_t s);
 int launch_swap_axes(const float2 *in, float2 *out, size_t a, size_t b, size_t c, int tw_log2,
                      unsigned long long row0, int direction, hipStream_t s);
 int launch_transpose_blocks(const float2 *in, float2 *out, size_t blocks, size_t rows, size_t cols, hipStream_t s);

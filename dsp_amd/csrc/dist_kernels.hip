@@ -20,14 +20,6 @@ namespace {
 
 constexpr int kDistThreads = 256;
 
-template <int SIGN>
-DSP_DEV c32 unit_root_wide(unsigned long long num, int log2den) {
-    // exponents here reach 2^30 and more: evaluate the angle in double (exact dyadic fraction)
-    double sn, cs;
-    sincospi(static_cast<double>(num) * __builtin_ldexp(2.0, -log2den), &sn, &cs);
-    return mk(static_cast<float>(cs), static_cast<float>(SIGN > 0 ? sn : -sn));
-}
-
 // two complex values per thread (16-byte accesses); C is even
 template <int SIGN, bool TW>
 __global__ __launch_bounds__(kDistThreads) void swap_axes_kernel(const float4 *__restrict__ in, float4 *__restrict__ out,

@@ -195,6 +195,15 @@ DSP_DEV c32 unit_root(unsigned num, int log2den) {
     return mk(cs, SIGN > 0 ? sn : -sn);
 }
 
+// The same for exponents beyond 2^24 (the inter-step twiddle of a 2^30-point transform): the angle is an exact
+// dyadic fraction in double.
+template <int SIGN>
+DSP_DEV c32 unit_root_wide(unsigned long long num, int log2den) {
+    double sn, cs;
+    sincospi(static_cast<double>(num) * __builtin_ldexp(2.0, -log2den), &sn, &cs);
+    return mk(static_cast<float>(cs), static_cast<float>(SIGN > 0 ? sn : -sn));
+}
+
 // One Stockham pass on the P register-resident points of a thread.
 //   N = 2^LOG2N points per transform, T = N/P threads per transform, `lt` = this thread's
 //   index inside its transform.  r[m] holds element lt + T*m of the pass input.

@@ -140,6 +140,17 @@ struct ColumnPlan {
     size_t s_hi;   // output stride of b / Bi
     size_t s_k;    // output stride of k
     int tw_log2;   // log2 of the twiddle modulus, 0 = no twiddle
+    // Optional generalisations (0 = the plain layout above), used by the fused "unpack . twiddle -> row FFT -> pack"
+    // phase of the distributed transform, where the row axis is cut into per-rank blocks on both sides:
+    size_t in_a = 0;      // input stride of a                                   (default L*B)
+    size_t in_lo = 0;     // input stride of l & (2^in_split - 1)                  (default B)
+    size_t in_hi = 0;     // input stride of l >> in_split                       (0: l is not split)
+    int in_split = 0;
+    int in_tw_log2 = 0;   // input element (a, l, b) is first multiplied by W^{(in_tw_row0 + a) * (l*B + b)}
+    unsigned long long in_tw_row0 = 0;
+    size_t out_a = 0;     // output stride of a                                  (default L*B)
+    size_t out_hi = 0;    // natural-order store: k -> (k >> out_split)*out_hi + (k & (2^out_split - 1))*s_k
+    int out_split = 0;
 };
 
 template <int R, int NS, int LOG2L, int C>
@@ -174,11 +185,35 @@ __global__ __launch_bounds__(TH) void fft_column_kernel(const c32 *__restrict__ 
     const size_t tiles_per_a = columns_per_a / C;
     const size_t a = tile / tiles_per_a;
     const size_t b = (tile % tiles_per_a) * C + c;
-    const c32 *src = in + a * L * plan.B + b;
+    const size_t in_lo = plan.in_lo ? plan.in_lo : plan.B;
+    const c32 *src = in + a * (plan.in_a ? plan.in_a : L * plan.B) + b;
 
     c32 r[kPoints];
+    if (plan.in_hi) {
+        const unsigned mask = (1u << plan.in_split) - 1u;
 #pragma unroll
-    for (int m = 0; m < kPoints; ++m) r[m] = src[static_cast<size_t>(lt + T * m) * plan.B];
+        for (int m = 0; m < kPoints; ++m) {
+            const unsigned l = lt + T * m;
+            r[m] = src[static_cast<size_t>(l >> plan.in_split) * plan.in_hi + static_cast<size_t>(l & mask) * in_lo];
+        }
+    } else {
+#pragma unroll
+        for (int m = 0; m < kPoints; ++m) r[m] = src[static_cast<size_t>(lt + T * m) * in_lo];
+    }
+    if (plan.in_tw_log2 > 0) {
+        // W^{k1 * n2}, n2 = (lt + T*m)*B + b:  W^{k1*(lt*B + b)} * (W^{k1*T*B})^m, the two roots from exact
+        // double angles (exponents reach 2^30), the powers by a product tree
+        const unsigned long long mask = (1ull << plan.in_tw_log2) - 1ull;
+        const unsigned long long k1 = plan.in_tw_row0 + a;
+        const c32 w0 = unit_root_wide<SIGN>((k1 * (static_cast<unsigned long long>(lt) * plan.B + b)) & mask, plan.in_tw_log2);
+        c32 pw[kPoints];
+        pw[1] = unit_root_wide<SIGN>((k1 * (static_cast<unsigned long long>(T) * plan.B)) & mask, plan.in_tw_log2);
+#pragma unroll
+        for (int m = 2; m < kPoints; ++m) pw[m] = cmul(pw[m >> 1], pw[m - (m >> 1)]);
+        r[0] = cmul(r[0], w0);
+#pragma unroll
+        for (int m = 1; m < kPoints; ++m) r[m] = cmul(r[m], cmul(w0, pw[m]));
+    }
 
     constexpr int R0 = radix_at(LOG2L, 0), R1 = radix_at(LOG2L, 1);
     stockham_pass<R0, 1, LOG2L, SIGN, kPoints>(r, lt);
@@ -210,7 +245,7 @@ __global__ __launch_bounds__(TH) void fft_column_kernel(const c32 *__restrict__ 
         for (int m = 0; m < kPoints; ++m) lds[c * (L + 1) + lt + T * m] = r[m];
         __syncthreads();
         const size_t b0 = (tile % tiles_per_a) * C;
-        c32 *base = out + a * L * plan.B + b0 * plan.s_hi;
+        c32 *base = out + a * (plan.out_a ? plan.out_a : L * plan.B) + b0 * plan.s_hi;
 #pragma unroll
         for (int m = 0; m < kPoints; ++m) {
             const int i = tid + TH * m;
@@ -219,7 +254,16 @@ __global__ __launch_bounds__(TH) void fft_column_kernel(const c32 *__restrict__ 
         }
         return;
     }
-    c32 *dst = out + a * L * plan.B + bhi * plan.s_hi + blo;
+    c32 *dst = out + a * (plan.out_a ? plan.out_a : L * plan.B) + bhi * plan.s_hi + blo;
+    if (plan.out_hi) {
+        const unsigned mask = (1u << plan.out_split) - 1u;
+#pragma unroll
+        for (int m = 0; m < kPoints; ++m) {
+            const unsigned k = lt + T * m;
+            dst[static_cast<size_t>(k >> plan.out_split) * plan.out_hi + static_cast<size_t>(k & mask) * plan.s_k] = r[m];
+        }
+        return;
+    }
 #pragma unroll
     for (int m = 0; m < kPoints; ++m) {
         const unsigned k = lt + T * m;
@@ -393,6 +437,46 @@ int launch_fft_columns(const float2 *in_f2, float2 *out_f2, int log2n, size_t co
     if (int rc = launch_column(la, in, scratch, p1, 1, direction, s)) return rc;
     const ColumnPlan p2{na * cols, na * cols, 0, na * cols, 0};
     return launch_column(lb, scratch, out, p2, 1, direction, s);
+}
+
+// The middle phase of the distributed transform in two passes instead of four (dsp_amd/dist_fft.py):
+//   in  [G][R][C]  block g = the columns n2 in [g*C, (g+1)*C) of my R rows (row r is k1 = row0 + r)
+//   out [G][R][C]  block g = the columns k2 in [g*C, (g+1)*C) of  Z[r][k2] = sum_n2 W_N2^{n2 k2} W_N^{n2 k1} in[r][n2]
+// N2 = G*C = N2a*N2b.  Pass 1 reads straight out of the received blocks (row axis split per rank), applies the
+// inter-step twiddle on load, transforms over n2a and stores [r][n2b][k2a]; pass 2 transforms over n2b and
+// stores straight into the blocks to send.
+int launch_fft_rows_exchange(const float2 *in_f2, float2 *out_f2, int log2n2, size_t rows, size_t world, int tw_log2n,
+                             unsigned long long row0, int direction, hipStream_t s) {
+    const c32 *in = reinterpret_cast<const c32 *>(in_f2);
+    c32 *out = reinterpret_cast<c32 *>(out_f2);
+    const int la = (log2n2 + 1) / 2, lb = log2n2 - la;
+    const size_t n2 = static_cast<size_t>(1) << log2n2, na = static_cast<size_t>(1) << la, nb = static_cast<size_t>(1) << lb;
+    if (la > 8 || lb < 4 || world == 0 || (world & (world - 1)) || n2 % world)
+        return fail(DSP_GPU_EUNSUPPORTED, "fft_rows_exchange: 2^%d columns over %zu ranks", log2n2, world);
+    const size_t C = n2 / world;
+    const size_t cols1 = (la >= 7 && nb % (2 * kTile / na) == 0 ? 2 : 1) * kTile / na;  // columns per workgroup, pass 1
+    const size_t cols2 = (lb >= 7 && na % (2 * kTile / nb) == 0 ? 2 : 1) * kTile / nb;
+    if (C < na || nb % cols1 || na % cols2 || in == out)
+        return fail(DSP_GPU_EUNSUPPORTED, "fft_rows_exchange: shape not covered by the fused passes");
+    void *scratch_v = nullptr;
+    if (int rc = workspace(WS_SCRATCH_A, rows * n2 * sizeof(c32), &scratch_v)) return rc;
+    c32 *scratch = static_cast<c32 *>(scratch_v);
+    int ilog = 0, olog = 0;
+    while ((nb << ilog) < C) ++ilog;  // n2a values per received block
+    while ((na << olog) < C) ++olog;  // k2b values per block to send
+    ColumnPlan p1{nb, 1, na, 1, log2n2};
+    p1.in_a = C;
+    p1.in_lo = nb;
+    p1.in_hi = rows * C;
+    p1.in_split = ilog;
+    p1.in_tw_log2 = tw_log2n;
+    p1.in_tw_row0 = row0;
+    if (int rc = launch_column(la, in, scratch, p1, rows, direction, s)) return rc;
+    ColumnPlan p2{na, na, 0, na, 0};
+    p2.out_a = C;
+    p2.out_hi = rows * C;
+    p2.out_split = olog;
+    return launch_column(lb, scratch, out, p2, rows, direction, s);
 }
 
 int launch_fft_real_batch(const float *in, size_t n_in, size_t in_stride, float2 *out_f2, int log2n, size_t batch,

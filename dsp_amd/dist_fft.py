@@ -8,6 +8,7 @@ n = n1*N2 + n2, k = k1 + N1*k2 and W_M = exp(+-2 pi i / M) (+ for the reference'
 
     pack -> [all-to-all] -> FFT over n1 -> [all-to-all] -> unpack * twiddle -> FFT over n2
          -> pack -> [all-to-all] -> transpose to natural order
+(the middle phase runs as two fused HBM passes, dsp_gpu_fft_rows_exchange, where the shape allows)
 
 The exchange is the only collective on the whole hot path; it is point-to-point by nature (every
 pair of GPUs trades one block), which is what the xGMI mesh wants: `all_to_all_single` over RCCL,
@@ -78,6 +79,16 @@ class GpuLocalOps:
                                                           int(inverse), self.capi.MEM_DEVICE, self._stream(t)))
         return out
 
+    def fft_rows_exchange(self, t, rows, n2, world, tw_log2n, row0, inverse=False):
+        """unpack * twiddle -> row FFT -> pack in two fused passes; None when the shape is not covered."""
+        out = self.torch.empty_like(t)
+        rc = self.capi.lib().dsp_gpu_fft_rows_exchange(t.data_ptr(), out.data_ptr(), n2.bit_length() - 1, rows, world,
+                                                       tw_log2n, row0, int(inverse), self._stream(t))
+        if rc == self.capi.EUNSUPPORTED:
+            return None
+        self.capi.check(rc)
+        return out
+
     def transpose_blocks(self, t, blocks, rows, cols):
         out = self.torch.empty_like(t)
         self.capi.check(self.capi.lib().dsp_gpu_transpose_blocks(t.data_ptr(), out.data_ptr(), blocks, rows, cols,
@@ -99,6 +110,11 @@ def phases(plan: Plan, rank: int, ops, inverse: bool):
         return ops.fft_columns(recv, plan.n1, C, inverse)
 
     def transform_n2(recv):       # [G][R][C] -> [R][N2] with W_N^{k1 n2}; FFT over n2; pack columns k2 by rank
+        fused = getattr(ops, "fft_rows_exchange", None)
+        if fused is not None:     # the three steps in two HBM passes where the kernels cover the shape
+            out = fused(recv, R, plan.n2, G, plan.log2n, rank * R, inverse)
+            if out is not None:
+                return out
         rows = ops.swap_axes(recv, G, R, C, tw_log2n=plan.log2n, row0=rank * R, inverse=inverse)
         spec = ops.fft_rows(rows, R, plan.n2, inverse)
         return ops.swap_axes(spec, R, G, C)

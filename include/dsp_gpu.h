@@ -160,11 +160,20 @@ int dsp_gpu_iir_multi(const float *x, float *y, size_t channels, size_t n, const
  *                             multiplied by W^{(tw_row0 + b) * (a*c_extent + c)}, W = e^{+-2 pi i / 2^tw_log2n}
  *                             (sign by `direction`): the inter-step twiddle fused into the unpack
  *   dsp_gpu_transpose_blocks  out[col][blk][row] = in[blk][row][col]
+ *   dsp_gpu_fft_rows_exchange the whole middle phase in two HBM passes: in = the `world` received blocks
+ *                             [world][rows][C] (block g holds columns n2 in [g*C, (g+1)*C) of my rows, row r
+ *                             being k1 = tw_row0 + r), out = the blocks to send, [world][rows][C] with
+ *                             Z[r][k2] = sum_n2 W_N2^{n2 k2} W_N^{n2 k1} in[r][n2], N2 = world*C = 2^log2n2,
+ *                             N = 2^tw_log2n.  Equals swap_axes(twiddle) -> fft_batch over rows -> swap_axes.
+ *                             DSP_GPU_EUNSUPPORTED for shapes the fused passes do not cover (2^12 <= N2 <= 2^16,
+ *                             C >= 2^ceil(log2n2/2)): callers fall back to the three separate steps.
  */
 int dsp_gpu_fft_columns(const void *in, void *out, int log2n, size_t cols, int direction, void *stream);
 int dsp_gpu_swap_axes(const void *in, void *out, size_t a, size_t b, size_t c, int tw_log2n, size_t tw_row0,
                       int direction, void *stream);
 int dsp_gpu_transpose_blocks(const void *in, void *out, size_t blocks, size_t rows, size_t cols, void *stream);
+int dsp_gpu_fft_rows_exchange(const void *in, void *out, int log2n2, size_t rows, size_t world, int tw_log2n,
+                              size_t tw_row0, int direction, void *stream);
 
 /* housekeeping */
 int dsp_gpu_device_count(void);
