@@ -525,7 +525,6 @@ int launch_fir_direct(const float *x, float *y, size_t channels, size_t n, const
 }
 
 int launch_fir_spectrum(const float *d_taps, int ntaps, float2 *d_hspec_f2, hipStream_t s) {
-    c32 *d_hspec = reinterpret_cast<c32 *>(d_hspec_f2);
     // FORWARD transform of the taps zero padded to 4096 points (the real-input wrapper does the padding)
     return launch_fft_real_batch(d_taps, static_cast<size_t>(ntaps), static_cast<size_t>(ntaps), d_hspec_f2, kOsLog2N, 1,
                                  DSP_GPU_FORWARD, 0, s);
