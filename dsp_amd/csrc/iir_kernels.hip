@@ -369,8 +369,9 @@ __global__ __launch_bounds__(kSt) void iir_scan_kernel(const float *__restrict__
                                                        const double *__restrict__ state_in,
                                                        double *__restrict__ state_out, double *__restrict__ tile_z,
                                                        const double *__restrict__ tile_c, unsigned ntiles, int warm,
-                                                       int levels, const double *__restrict__ hrow) {
+                                                       int levels, const double *__restrict__ hrow, int carry_terms) {
     constexpr int W = kWords<P, WIDE>;
+    constexpr int MS = W * P;
     __shared__ __attribute__((aligned(16))) float xs[(kSt + 1) * kRowPad];
     const int tid = threadIdx.x;
     const size_t ch = blockIdx.y;
@@ -455,8 +456,26 @@ __global__ __launch_bounds__(kSt) void iir_scan_kernel(const float *__restrict__
     // carry into the tile
     SVec<P, WIDE> carry;
     sv_zero<P, WIDE>(carry);
-    if (MODE == SCAN_APPLY) sv_load<P, WIDE>(carry, tile_c + (ch * ntiles + tile) * W);
-    else if (MODE == SCAN_FUSED && tile == 0 && sin_c)
+    if (MODE == SCAN_APPLY) {
+        if (carry_terms > 0) {
+            // C_k = Z_{k-1} + MT (Z_{k-2} + MT (Z_{k-3} + ...)): the tile matrix MT = A^4096 of a stable filter decays so
+            // fast that a handful of terms is exact to 2^-60 (host), so every tile builds its own carry from the
+            // end states the REDUCE pass left and the serial carry kernel is not needed ("Z_{-1}" = caller's state)
+            for (int j = carry_terms; j >= 1; --j) {
+                const long long kk = static_cast<long long>(tile) - j;
+                SVec<P, WIDE> nxt;
+                sv_zero<P, WIDE>(nxt);
+                if (kk >= 0) sv_load<P, WIDE>(nxt, tile_z + (ch * ntiles + kk) * W);
+                else if (kk == -1 && sin_c)
+#pragma unroll
+                    for (int i = 0; i < P; ++i) nxt.hi[i] = sin_c[P + i];
+                sv_mat_acc<P, WIDE>(nxt, mats + 9 * MS, carry);
+                carry = nxt;
+            }
+        } else {
+            sv_load<P, WIDE>(carry, tile_c + (ch * ntiles + tile) * W);
+        }
+    } else if (MODE == SCAN_FUSED && tile == 0 && sin_c)
 #pragma unroll
         for (int i = 0; i < P; ++i) carry.hi[i] = sin_c[P + i];
     if (tid == 0) sv_mat_acc<P, WIDE>(S, mats, carry);
@@ -532,12 +551,15 @@ __global__ __launch_bounds__(kSt) void iir_scan_kernel(const float *__restrict__
 }
 
 // Exclusive scan of the tile end states: C_0 = initial state, C_k = Z_{k-1} + MT C_{k-1}.
-// mats2: slot [0] = MT = A^8192, [1 + j] = MT^(G * 2^j); thread t owns tiles [t G, (t+1) G).
+// mats2: slot [0] = MT = A^kTile, [1 + j] = MT^(G * 2^j).  Workgroup (ch, w) owns tiles [w*tiles_per_wg, ...), its
+// thread t the G tiles from w*tiles_per_wg + t*G.  The carry into a workgroup's first tile comes from `warm`
+// tiles of warm-up (host: ||MT^warm|| <= 2^-60, so the dropped older terms are below rounding) -- with one
+// workgroup per channel (warm = 0, the fallback for filters that decay slower than that) it is the caller's state.
 template <int P, bool WIDE>
 __global__ __launch_bounds__(kCt) void iir_carry_kernel(const double *__restrict__ tile_z, double *__restrict__ tile_c,
                                                          const double *__restrict__ mats2,
                                                          const double *__restrict__ state_in, unsigned ntiles,
-                                                         unsigned G) {
+                                                         unsigned G, unsigned tiles_per_wg, unsigned warm) {
     constexpr int W = kWords<P, WIDE>;
     constexpr int MS = W * P;
     __shared__ double sbuf[W * kCt];
@@ -545,13 +567,25 @@ __global__ __launch_bounds__(kCt) void iir_carry_kernel(const double *__restrict
     const size_t ch = blockIdx.x;
     const double *z = tile_z + ch * ntiles * W;
     double *c = tile_c + ch * ntiles * W;
-    const unsigned k0 = tid * G, k1 = min(ntiles, k0 + G);
+    const unsigned base = blockIdx.y * tiles_per_wg, end = min(ntiles, base + tiles_per_wg);
+    const unsigned k0 = min(end, base + tid * G), k1 = min(end, k0 + G);
 
     SVec<P, WIDE> s;
     sv_zero<P, WIDE>(s);
-    if (tid == 0 && state_in)
+    if (tid == 0) {
+        if (base == 0) {
+            if (state_in)
 #pragma unroll
-        for (int i = 0; i < P; ++i) s.hi[i] = state_in[ch * 2 * P + P + i];
+                for (int i = 0; i < P; ++i) s.hi[i] = state_in[ch * 2 * P + P + i];
+        } else {
+            for (unsigned k = base - warm; k < base; ++k) {  // base >= tiles_per_wg >= warm
+                SVec<P, WIDE> nxt;
+                sv_load<P, WIDE>(nxt, z + static_cast<size_t>(k) * W);
+                sv_mat_acc<P, WIDE>(nxt, mats2, s);
+                s = nxt;
+            }
+        }
+    }
     const SVec<P, WIDE> first = s;
     for (unsigned k = k0; k < k1; ++k) {
         SVec<P, WIDE> nxt;
@@ -680,8 +714,25 @@ int scan_launch(const float *x, float *y, size_t channels, size_t n, const IirCo
     unsigned ntiles;
     if (fused) ntiles = n <= static_cast<size_t>(kTile) ? 1u : 1u + static_cast<unsigned>((n - kTile + (kTile - warm) - 1) / (kTile - warm));
     else ntiles = static_cast<unsigned>((n + kTile - 1) / kTile);
-    const unsigned G = (ntiles + kCt - 1) / kCt;
+    unsigned G = (ntiles + kCt - 1) / kCt, tiles_per_wg = ntiles, carry_warm = 0;
+    int carry_terms = 0;  // > 0: MT^carry_terms is negligible and small: tiles sum their own carries, no carry kernel
     if (!fused) {
+        Mat pw = MT;
+        int decay = 0;  // smallest j <= 64 with ||MT^j|| <= 2^-60 (0: slower than that)
+        for (int j = 1; j <= 64; ++j) {
+            if (mat_norm_inf(pw, P) <= 0x1p-60) {
+                decay = j;
+                break;
+            }
+            pw = mat_mul(pw, MT, P);
+        }
+        if (decay > 0 && decay <= 2) carry_terms = decay;
+        constexpr unsigned kCarryG = 4;  // tiles per thread when the carry scan is cut into workgroups
+        if (decay > 0 && ntiles > 4 * kCt * kCarryG) {
+            G = kCarryG;
+            tiles_per_wg = kCt * kCarryG;  // 1024 >= 64 >= decay
+            carry_warm = static_cast<unsigned>(decay);
+        }
         store_mat(table, 9, MT, P, WIDE);
         Mat mg = mat_pow(MT, G, P);
         for (int j = 0; j < kCtLevels; ++j) {
@@ -699,7 +750,7 @@ int scan_launch(const float *x, float *y, size_t channels, size_t n, const IirCo
     const dim3 grid(8u * std::min((ntiles + 7u) / 8u, 32u * kScanWgsPerCu), static_cast<unsigned>(channels));
     if (fused) {
         hipLaunchKernelGGL((iir_scan_kernel<P, SCAN_FUSED, ALIGNED, WIDE>), grid, dim3(kSt), 0, s, x, y, n, co, d_table,
-                           state_in, state, nullptr, nullptr, ntiles, warm, levels, d_table + 18 * ms);
+                           state_in, state, nullptr, nullptr, ntiles, warm, levels, d_table + 18 * ms, 0);
         return check_launch("iir_scan_kernel<fused>");
     }
     void *z_v = nullptr, *c_v = nullptr;
@@ -708,13 +759,19 @@ int scan_launch(const float *x, float *y, size_t channels, size_t n, const IirCo
     if (int rc = workspace(WS_SCRATCH_B, carry_bytes, &c_v)) return rc;
     double *tz = static_cast<double *>(z_v), *tc = static_cast<double *>(c_v);
     hipLaunchKernelGGL((iir_scan_kernel<P, SCAN_REDUCE, ALIGNED, WIDE>), grid, dim3(kSt), 0, s, x, y, n, co, d_table,
-                       state_in, nullptr, tz, nullptr, ntiles, 0, levels, d_table + 18 * ms);
+                       state_in, nullptr, tz, nullptr, ntiles, 0, levels, d_table + 18 * ms, 0);
     if (int rc = check_launch("iir_scan_kernel<reduce>")) return rc;
-    hipLaunchKernelGGL((iir_carry_kernel<P, WIDE>), dim3(static_cast<unsigned>(channels)), dim3(kCt), 0, s, tz, tc,
-                       d_table + 9 * ms, state_in, ntiles, G);
+    if (carry_terms > 0) {  // every tile sums its own few carry terms
+        hipLaunchKernelGGL((iir_scan_kernel<P, SCAN_APPLY, ALIGNED, WIDE>), grid, dim3(kSt), 0, s, x, y, n, co, d_table,
+                           state_in, state, tz, nullptr, ntiles, 0, levels, d_table + 18 * ms, carry_terms);
+        return check_launch("iir_scan_kernel<apply, local carries>");
+    }
+    const unsigned carry_wgs = (ntiles + tiles_per_wg - 1) / tiles_per_wg;
+    hipLaunchKernelGGL((iir_carry_kernel<P, WIDE>), dim3(static_cast<unsigned>(channels), carry_wgs), dim3(kCt), 0, s, tz, tc,
+                       d_table + 9 * ms, state_in, ntiles, G, tiles_per_wg, carry_warm);
     if (int rc = check_launch("iir_carry_kernel")) return rc;
     hipLaunchKernelGGL((iir_scan_kernel<P, SCAN_APPLY, ALIGNED, WIDE>), grid, dim3(kSt), 0, s, x, y, n, co, d_table,
-                       state_in, state, nullptr, tc, ntiles, 0, levels, d_table + 18 * ms);
+                       state_in, state, nullptr, tc, ntiles, 0, levels, d_table + 18 * ms, 0);
     return check_launch("iir_scan_kernel<apply>");
 }
 

@@ -8,7 +8,8 @@ y = torch.empty_like(x)
 for ntaps in (15, 31, 63, 95, 127, 191, 255, 511, 1023, 2047):
     h = design.sinc(0.1, ntaps)
     row = [f"taps {ntaps:5d}"]
-    for mode in ("direct", "overlap_save"):
+    for mode in ("direct", "direct_valu", "overlap_save"):
+        if mode == "direct_valu" and ntaps > 1024: continue
         for _ in range(2): ops.convolve(x, h, mode, out=y)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

@@ -317,3 +317,23 @@ def test_iir_multi_filter_bank(ops, dev, orc, channels, n):
     a, b = orc.chebyshev(0.1, 4)
     rep = lambda v: t(np.tile(v, (channels, 1)))
     assert torch.equal(ops.iir_multi(xd, rep(a), rep(b)), ops.iir(xd, a, b, mode="batch"))
+
+
+@pytest.mark.parametrize("fc", [0.01, 0.001])
+def test_scan_many_tiles_slow_filters(ops, dev, fc):
+    """Slow-decaying sections over enough tiles (8,193) that the tile carries are scanned by several workgroups with
+    warm-up tiles (fc = 0.001) or summed locally from the last tile or two (fc = 0.01): against the sequential
+    kernel on the same channel, carried state in and out."""
+    import torch
+    from dsp_amd import design
+    a, b = design.chebyshev(fc, 4)
+    n = (1 << 25) + 777
+    g = torch.Generator(device=dev).manual_seed(int(fc * 1e4))
+    x = torch.randn(1, n, device=dev, generator=g)
+    st0 = torch.tensor([[0.3, -0.2, 0.1, 0.05, 0.4, 0.35, 0.3, 0.25]], dtype=torch.float64, device=dev)
+    st_scan, st_seq = st0.clone(), st0.clone()
+    y_scan = ops.iir(x, a, b, state=st_scan, mode="scan")
+    y_seq = ops.iir(x, a, b, state=st_seq, mode="batch")
+    err = torch.linalg.vector_norm((y_scan - y_seq).double()) / torch.linalg.vector_norm(y_seq.double())
+    assert float(err) <= 2e-6, float(err)
+    assert torch.allclose(st_scan, st_seq, rtol=1e-6, atol=1e-9)
