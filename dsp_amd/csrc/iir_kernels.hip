@@ -323,12 +323,23 @@ DSP_DEV void sv_mat_acc(SVec<P, WIDE> &s, const double *__restrict__ M, const SV
 #pragma unroll
     for (int r = 0; r < P; ++r) {
         if (WIDE) {
-            DD acc{s.hi[r], s.lo[r]};
+            // compensated dot product: exact two-product of the leading parts, cross terms and every rounding
+            // error gathered in `lo`, one renormalisation per row (12 instead of 19 operations per term)
+            double hi = s.hi[r], lo = s.lo[r];
 #pragma unroll
-            for (int c = 0; c < P; ++c)
-                acc = dd_add(acc, dd_mul(DD{M[r * P + c], M[P * P + r * P + c]}, DD{o.hi[c], o.lo[c]}));
-            s.hi[r] = acc.hi;
-            s.lo[r] = acc.lo;
+            for (int c = 0; c < P; ++c) {
+                const double mh = M[r * P + c], ml = M[P * P + r * P + c];
+                const double p = mh * o.hi[c];
+                double e = fma(mh, o.hi[c], -p);
+                e = fma(mh, o.lo[c], e);
+                e = fma(ml, o.hi[c], e);
+                const DD t = dd_two_sum(hi, p);
+                hi = t.hi;
+                lo += t.lo + e;
+            }
+            const double h2 = hi + lo;
+            s.lo[r] = lo - (h2 - hi);
+            s.hi[r] = h2;
         } else {
             double acc = s.hi[r];
 #pragma unroll
