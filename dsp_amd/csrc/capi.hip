@@ -238,6 +238,14 @@ int dsp_gpu_fft_real_batch(const float *in, size_t n_in, size_t in_stride, void 
 }
 
 // shared by the one-shot and the streaming form; `history` == nullptr: one-shot (filter.h:123-140)
+// Device buffers that overlap would have one workgroup overwrite samples another still has to read (FIR history,
+// window and warm-up samples reach back across tile borders); host buffers are staged and may alias.
+static bool device_overlap(const void *a, const void *b, size_t bytes, int mem) {
+    if (mem != DSP_GPU_MEM_DEVICE) return false;
+    const char *p = static_cast<const char *>(a), *q = static_cast<const char *>(b);
+    return p < q + bytes && q < p + bytes;
+}
+
 static int convolve_impl(const char *who, const float *x, float *y, size_t channels, size_t n, const float *taps,
                          int ntaps, float *history, unsigned long long position, int mode, int mem, void *stream) {
     if (!x || !y || !taps) return fail(DSP_GPU_EINVAL, "%s: null buffer", who);
@@ -251,6 +259,8 @@ static int convolve_impl(const char *who, const float *x, float *y, size_t chann
         return fail(DSP_GPU_EINVAL, "%s: overlap-save supports at most 2049 taps, got %d", who, ntaps);
     if (bad_mem(mem)) return fail(DSP_GPU_EINVAL, "%s: mem %d", who, mem);
     if (channels == 0 || n == 0) return DSP_GPU_OK;
+    if (device_overlap(x, y, channels * n * sizeof(float), mem))
+        return fail(DSP_GPU_EINVAL, "%s: x and y overlap (the filter is not in-place on device buffers)", who);
     if (mode == DSP_GPU_CONV_AUTO)  // long filters on long signals amortise the FFT blocks
         mode = (ntaps >= 64 && ntaps <= 2049 && n >= 4096) ? DSP_GPU_CONV_OVERLAP_SAVE : DSP_GPU_CONV_DIRECT;
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -314,6 +324,8 @@ int dsp_gpu_moving_average(const float *x, float *y, size_t channels, size_t n, 
         return fail(DSP_GPU_EINVAL, "dsp_gpu_moving_average: n %zu < npoints %d (the reference reads out of bounds)", n, npoints);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t bytes = channels * n * sizeof(float);
+    if (device_overlap(x, y, bytes, mem))
+        return fail(DSP_GPU_EINVAL, "dsp_gpu_moving_average: x and y overlap (not in-place on device buffers)");
     if (mem == DSP_GPU_MEM_DEVICE) return launch_moving_average(x, y, channels, n, npoints, s);
     HostStage hs;
     if (int rc = stage_in(x, bytes, bytes, s, &hs)) return rc;
@@ -346,6 +358,13 @@ int dsp_gpu_iir(const float *x, float *y, size_t channels, size_t n, const doubl
         mode = (channels < 8192 && n >= 65536 && poles <= 8) ? DSP_GPU_IIR_SCAN : DSP_GPU_IIR_BATCH;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t bytes = channels * n * sizeof(float);
+    if (device_overlap(x, y, bytes, mem)) {
+        // the sequential kernel reads every tile before it writes it, so y == x is fine there; the scan's warm-up
+        // samples are not (AUTO then takes the sequential kernel)
+        if (x != y || (mode == DSP_GPU_IIR_SCAN && !auto_mode))
+            return fail(DSP_GPU_EINVAL, "dsp_gpu_iir: x and y overlap (only y == x in BATCH mode is in-place)");
+        mode = DSP_GPU_IIR_BATCH;
+    }
     const size_t state_bytes = channels * 2 * static_cast<size_t>(poles) * sizeof(double);
     const float *dx = x;
     float *dy = y;

@@ -337,3 +337,28 @@ def test_scan_many_tiles_slow_filters(ops, dev, fc):
     err = torch.linalg.vector_norm((y_scan - y_seq).double()) / torch.linalg.vector_norm(y_seq.double())
     assert float(err) <= 2e-6, float(err)
     assert torch.allclose(st_scan, st_seq, rtol=1e-6, atol=1e-9)
+
+
+def test_aliasing_rules(ops, dev, orc):
+    """y == x is in-place in BATCH mode (and AUTO picks it); overlapping device buffers are refused elsewhere."""
+    import torch
+    from dsp_amd import capi
+    a, b = orc.chebyshev(0.1, 4)
+    x = torch.randn(3, 70000, device=dev)
+    want = ops.iir(x, a, b, mode="batch")
+    for mode in ("batch", "auto"):
+        buf = x.clone()
+        ops.iir(buf, a, b, mode=mode, out=buf)
+        assert torch.equal(buf, want)
+    with pytest.raises(capi.DspGpuError):
+        buf = x.clone()
+        ops.iir(buf, a, b, mode="scan", out=buf)
+    big = torch.randn(3 * 70000 + 100, device=dev)
+    with pytest.raises(capi.DspGpuError):
+        ops.iir(big[:210000].view(3, 70000), a, b, mode="batch", out=big[100:210100].view(3, 70000))
+    with pytest.raises(capi.DspGpuError):
+        ops.convolve(big[:210000].view(3, 70000), np.ones(5), out=big[:210000].view(3, 70000))
+    with pytest.raises(capi.DspGpuError):
+        ops.moving_average(big[:210000].view(3, 70000), 5, out=big[4:210004].view(3, 70000))
+    h = np.ascontiguousarray(x.cpu().numpy())
+    assert np.array_equal(ops.iir(h, a, b, mode="scan", out=h), ops.iir(x, a, b, mode="scan").cpu().numpy())  # host buffers are staged
