@@ -17,6 +17,10 @@ DSP_DEV int padded(int i) { return i + (i >> 4); }
 // Scatter the outputs of the pass (radix R, sub-length NS) to their Stockham positions, then
 // gather r[m] = element lt + T*m for the next pass.  `base` = first point of this thread's
 // transform inside the workgroup tile.
+// Where the padded index is linear in the register slot -- (x + 16k) >> 4 == (x >> 4) + k -- it is written as ONE
+// base plus compile-time offsets, so the slots become immediate offsets of ds_read/ds_write instead of sixteen
+// separately computed address registers (the compiler does not find this: ~100 integer VALU instructions per
+// 4096-point transform; the overlap-save FIR, which is VALU-bound, gained 7 %).
 template <int R, int NS, int LOG2N>
 DSP_DEV void lds_exchange(c32 (&r)[kPoints], c32 *lds, int lt, int base) {
     constexpr int T = (1 << LOG2N) / kPoints;
@@ -24,12 +28,24 @@ DSP_DEV void lds_exchange(c32 (&r)[kPoints], c32 *lds, int lt, int base) {
 #pragma unroll
     for (int s = 0; s < B; ++s) {
         const int j = lt + T * s;
+        if constexpr (NS % 16 == 0) {
+            c32 *w = lds + padded(base + stockham_dest<R, NS>(j, 0));
 #pragma unroll
-        for (int u = 0; u < R; ++u) lds[padded(base + stockham_dest<R, NS>(j, u))] = r[s + u * B];
+            for (int u = 0; u < R; ++u) w[u * (NS + NS / 16)] = r[s + u * B];
+        } else {
+#pragma unroll
+            for (int u = 0; u < R; ++u) lds[padded(base + stockham_dest<R, NS>(j, u))] = r[s + u * B];
+        }
     }
     __syncthreads();
+    if constexpr (T % 16 == 0) {
+        const c32 *g = lds + padded(base + lt);
 #pragma unroll
-    for (int m = 0; m < kPoints; ++m) r[m] = lds[padded(base + lt + T * m)];
+        for (int m = 0; m < kPoints; ++m) r[m] = g[m * (T + T / 16)];
+    } else {
+#pragma unroll
+        for (int m = 0; m < kPoints; ++m) r[m] = lds[padded(base + lt + T * m)];
+    }
 }
 
 // All passes of one transform.  In: r[m] = x[lt + T*m].  Out: r[m] = X[lt + T*m].
