@@ -32,6 +32,7 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 // ---------------------------------------------------------------------------------------------
 // direct FIR on fp32 MFMA
 // ---------------------------------------------------------------------------------------------
+constexpr size_t kMaxGridY = 65535;  // channels ride grid.y; longer batches are cut into several launches
 constexpr int kFirThreads = 256;
 constexpr int kFirWaves = kFirThreads / 64;
 constexpr int kFirTile = 256;      // outputs per 16x16 tile
@@ -497,7 +498,8 @@ int launch_fir_history(const float *x, size_t n, const float *old_hist, float *n
 int launch_fir_direct_valu(const float *x, float *y, size_t channels, size_t n, const float *d_taps, int ntaps,
                            hipStream_t s) {
     if (ntaps > 1024) return fail(DSP_GPU_EUNSUPPORTED, "direct FIR (VALU): at most 1024 taps, got %d", ntaps);
-    if (channels > 65535) return fail(DSP_GPU_EUNSUPPORTED, "direct FIR: more than 65535 channels per call");
+    for (; channels > kMaxGridY; channels -= kMaxGridY, x += kMaxGridY * n, y += kMaxGridY * n)  // grid.y is 16 bits
+        if (int rc = launch_fir_direct_valu(x, y, kMaxGridY, n, d_taps, ntaps, s)) return rc;
     const int taps_p = ((ntaps + 19) / 20) * 20;
     const int H = ((taps_p + 8 + 15) / 16) * 16;  // staged history: the window reaches base - 8 on its last prefetch
     const int S = H + kVfTile;
@@ -514,7 +516,10 @@ int launch_fir_direct(const float *x, float *y, size_t channels, size_t n, const
     const int Q = (order + 15) / 16 + 1;
     const size_t lds_bytes = (static_cast<size_t>(16 * (Q - 1) + kFirOutPerWg) + 4u * (16 * Q + 16)) * sizeof(float);
     const size_t blocks = (n + kFirOutPerWg - 1) / kFirOutPerWg;
-    if (channels > 65535) return fail(DSP_GPU_EUNSUPPORTED, "direct FIR: more than 65535 channels per call");
+    for (; channels > kMaxGridY; channels -= kMaxGridY, x += kMaxGridY * n, y += kMaxGridY * n) {  // grid.y is 16 bits
+        if (int rc = launch_fir_direct(x, y, kMaxGridY, n, d_taps, ntaps, hist, zero_head, s)) return rc;
+        if (hist) hist += kMaxGridY * static_cast<size_t>(order);
+    }
     const bool aligned = (n % 4 == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0) && (reinterpret_cast<uintptr_t>(y) % 16 == 0);
     auto kern = aligned ? fir_direct_kernel<true> : fir_direct_kernel<false>;
     if (lds_bytes > 64 * 1024)
@@ -550,7 +555,8 @@ int launch_fir_overlap_save(const float *x, float *y, size_t channels, size_t n,
 
 int launch_moving_average(const float *x, float *y, size_t channels, size_t n, int npoints, hipStream_t s) {
     if (npoints > 8192) return fail(DSP_GPU_EUNSUPPORTED, "moving average: npoints %d > 8192", npoints);
-    if (channels > 65535) return fail(DSP_GPU_EUNSUPPORTED, "moving average: more than 65535 channels per call");
+    for (; channels > kMaxGridY; channels -= kMaxGridY, x += kMaxGridY * n, y += kMaxGridY * n)  // grid.y is 16 bits
+        if (int rc = launch_moving_average(x, y, kMaxGridY, n, npoints, s)) return rc;
     const int window = 2 * (npoints / 2) + 1;
     // staged samples: tile + window, + 3 for the aligned start, + 1 so index `up` of the last output exists
     const int span = ((kMaTile + window + 4 + 15) / 16) * 16;

@@ -874,7 +874,11 @@ const ScanPlan *cached_plan(const IirCoef &co, ScanPlan &local) {
 template <int P, bool ALIGNED>
 int scan_dispatch(const float *x, float *y, size_t channels, size_t n, const IirCoef &co, double *state,
                   hipStream_t s) {
-    if (channels > 65535) return fail(DSP_GPU_EUNSUPPORTED, "IIR scan: more than 65535 channels per call");
+    constexpr size_t kMaxGridY = 65535;  // channels ride grid.y; longer batches are cut into several launches
+    for (; channels > kMaxGridY; channels -= kMaxGridY, x += kMaxGridY * n, y += kMaxGridY * n) {
+        if (int rc = scan_dispatch<P, ALIGNED>(x, y, kMaxGridY, n, co, state, s)) return rc;
+        if (state) state += kMaxGridY * 2 * P;
+    }
     ScanPlan plan;
     cached_plan(co, plan);
     if (!plan.usable)

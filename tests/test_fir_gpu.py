@@ -231,3 +231,30 @@ def test_direct_valu_matches(ops, dev, orc, ntaps, channels, n):
     assert rel_l2(g[1:-1], want) <= DIRECT_TOL
     assert not g[1:-1][:, : min(n, ntaps - 1)].any()
     assert rel_l2(ops.convolve(x, h, mode="direct_valu"), want) <= DIRECT_TOL  # host pointers
+
+
+def test_more_channels_than_one_grid(ops, dev, orc):
+    """70,000 short channels: the channel axis rides grid.y (16 bits), so the launchers cut it into slices."""
+    import torch
+    rng = np.random.default_rng(70)
+    channels, n = 70000, 96
+    x = rng.standard_normal((channels, n)).astype(np.float32)
+    h = orc.sinc(0.2, 9)[:9]
+    xd = torch.from_numpy(x).to(dev)
+    pick = [0, 1, 65534, 65535, 65536, 69999]
+    y = ops.convolve(xd, h, mode="direct").cpu().numpy()
+    assert rel_l2(y[pick], orc.fir(x[pick].astype(np.float64), h)) <= DIRECT_TOL
+    m = ops.moving_average(xd, 7).cpu().numpy()
+    assert rel_l2(m[pick], orc.moving_average(x[pick].astype(np.float64), 7)) <= 1e-6
+    a, b = orc.chebyshev(0.2, 2)
+    st = torch.zeros(channels, 4, dtype=torch.float64, device=dev)
+    s1 = ops.iir(xd, a, b, state=st, mode="scan").cpu().numpy()
+    assert rel_l2(s1[pick], orc.iir(x[pick].astype(np.float64), a, b)) <= 2e-6
+    assert torch.equal(st, _state_after(ops, xd, a, b))
+
+
+def _state_after(ops, xd, a, b):
+    import torch
+    st = torch.zeros(xd.shape[0], 4, dtype=torch.float64, device=xd.device)
+    ops.iir(xd, a, b, state=st, mode="batch")
+    return st
