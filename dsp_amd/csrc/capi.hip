@@ -170,7 +170,7 @@ extern "C" {
 
 int dsp_gpu_fft_batch(const void *in, void *out, int log2n, size_t batch, int direction, int mem, void *stream) {
     if (!in || !out) return fail(DSP_GPU_EINVAL, "dsp_gpu_fft_batch: null buffer");
-    if (log2n < 1 || log2n > 24) return fail(DSP_GPU_EINVAL, "dsp_gpu_fft_batch: log2n %d outside [1,24]", log2n);
+    if (log2n < 1 || log2n > 30) return fail(DSP_GPU_EINVAL, "dsp_gpu_fft_batch: log2n %d outside [1,30]", log2n);
     if (direction != DSP_GPU_FORWARD && direction != DSP_GPU_INVERSE)
         return fail(DSP_GPU_EINVAL, "dsp_gpu_fft_batch: direction %d", direction);
     if (bad_mem(mem)) return fail(DSP_GPU_EINVAL, "dsp_gpu_fft_batch: mem %d", mem);
@@ -190,7 +190,7 @@ int dsp_gpu_fft_batch(const void *in, void *out, int log2n, size_t batch, int di
 int dsp_gpu_fft_batch_timed(const void *in, void *out, int log2n, size_t batch, int direction, int iters,
                             float *ms_per_launch, void *stream) {
     if (!in || !out || !ms_per_launch || iters < 1) return fail(DSP_GPU_EINVAL, "dsp_gpu_fft_batch_timed: bad argument");
-    if (log2n < 1 || log2n > 24) return fail(DSP_GPU_EINVAL, "dsp_gpu_fft_batch_timed: log2n %d", log2n);
+    if (log2n < 1 || log2n > 30) return fail(DSP_GPU_EINVAL, "dsp_gpu_fft_batch_timed: log2n %d", log2n);
     hipStream_t s = static_cast<hipStream_t>(stream);
     hipEvent_t e0, e1;
     DSPGPU_HIP(hipEventCreate(&e0));
@@ -222,7 +222,7 @@ int dsp_gpu_fft_real_batch(const float *in, size_t n_in, size_t in_stride, void 
     // fft.h:62-63: log2n = ceil(log2(nf))
     int log2n = 0;
     while ((static_cast<size_t>(1) << log2n) < static_cast<size_t>(nf)) ++log2n;
-    if (log2n < 1 || log2n > 24) return fail(DSP_GPU_EINVAL, "dsp_gpu_fft_real_batch: padded size 2^%d unsupported", log2n);
+    if (log2n < 1 || log2n > 30) return fail(DSP_GPU_EINVAL, "dsp_gpu_fft_real_batch: padded size 2^%d unsupported", log2n);
     if (batch == 0) return DSP_GPU_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (mem == DSP_GPU_MEM_DEVICE)

@@ -228,9 +228,11 @@ __global__ __launch_bounds__(TH) void fft_column_kernel(const c32 *__restrict__ 
         // of sixteen sincos, which cost more VALU work than the transform itself
         const unsigned mask = (1u << plan.tw_log2) - 1u;
         const unsigned ub = static_cast<unsigned>(bhi);
-        const c32 w0 = unit_root<SIGN>((static_cast<unsigned>(lt) * ub) & mask, plan.tw_log2);
+        // moduli beyond 2^24 (transforms of more than 2^24 points) need the angle in double
+        const unsigned e0 = (static_cast<unsigned>(lt) * ub) & mask, e1 = (static_cast<unsigned>(T) * ub) & mask;
+        const c32 w0 = plan.tw_log2 > 24 ? unit_root_wide<SIGN>(e0, plan.tw_log2) : unit_root<SIGN>(e0, plan.tw_log2);
         c32 pw[kPoints];
-        pw[1] = unit_root<SIGN>((static_cast<unsigned>(T) * ub) & mask, plan.tw_log2);
+        pw[1] = plan.tw_log2 > 24 ? unit_root_wide<SIGN>(e1, plan.tw_log2) : unit_root<SIGN>(e1, plan.tw_log2);
 #pragma unroll
         for (int m = 2; m < kPoints; ++m) pw[m] = cmul(pw[m >> 1], pw[m - (m >> 1)]);
         r[0] = cmul(r[0], w0);
@@ -362,16 +364,15 @@ int launch_column(int log2l, const c32 *in, c32 *out, const ColumnPlan &plan, si
     return check_launch("fft_column_kernel");
 }
 
-// Large transform: N = N1*N2 (two column passes) or N1*N2*N3 (three), every factor <= 256.
-//   step 1  [n1][rest]      FFT over n1, twiddle W_N^{k1*rest}, transposed store -> [rest][k1]
-//   step 2  [n2][n3][k1]    FFT over n2, twiddle W_{N2N3}^{k2*n3}                -> [n3][k2][k1]
-//   step 3  [n3][k2 k1]     FFT over n3                                           -> [k3][k2 k1] = natural order
-// (with two factors step 2 is the last one and carries no twiddle).  Ping-pongs between
-// `out` and one scratch buffer so the input is never modified.
+// Large transform: N = N1*N2*...*NK, K = 2 (N <= 2^16), 3 (<= 2^24) or 4 (<= 2^30) column passes, every factor
+// <= 256.  Before step i the data is laid out [n_i][n_{i+1} .. n_K][k_{i-1} .. k_1]; the step transforms over
+// n_i, multiplies by W_{n_i * rest}^{k_i * r} (r = the index into n_{i+1} .. n_K, rest = their product; nothing on
+// the last step) and stores [n_{i+1} .. n_K][k_i][k_{i-1} .. k_1] -- after step K that is natural order.  The
+// passes ping-pong between `out` and one scratch buffer so that the input is never modified.
 int launch_large(const c32 *in, c32 *out, int log2n, size_t batch, int direction, hipStream_t s) {
     const size_t n = static_cast<size_t>(1) << log2n;
-    const int steps = log2n <= 16 ? 2 : 3;
-    int lg[3] = {0, 0, 0};
+    const int steps = log2n <= 16 ? 2 : (log2n <= 24 ? 3 : 4);
+    int lg[4] = {0, 0, 0, 0};
     for (int i = 0, left = log2n; i < steps; ++i) {
         lg[i] = (left + (steps - i) - 1) / (steps - i);
         left -= lg[i];
@@ -379,27 +380,23 @@ int launch_large(const c32 *in, c32 *out, int log2n, size_t batch, int direction
     void *scratch_v = nullptr;
     if (int rc = workspace(WS_SCRATCH_A, batch * n * sizeof(c32), &scratch_v)) return rc;
     c32 *scratch = static_cast<c32 *>(scratch_v);
-    const size_t n1 = static_cast<size_t>(1) << lg[0], n2 = static_cast<size_t>(1) << lg[1];
-    if (steps == 2) {
-        ColumnPlan p1{n2, 1, n1, 1, log2n};
-        if (int rc = launch_column(lg[0], in, scratch, p1, batch, direction, s)) return rc;
-        ColumnPlan p2{n1, n1, 0, n1, 0};
-        return launch_column(lg[1], scratch, out, p2, batch, direction, s);
+    // destination of pass i: the last one writes `out` and they alternate backwards; in place, the first pass
+    // may not write what it reads, so the chain starts in scratch and a copy finishes it if it ends there
+    const bool in_place = in == out;
+    const c32 *src = in;
+    int done_log2 = 0, rest_log2 = log2n;
+    for (int i = 0; i < steps; ++i) {
+        rest_log2 -= lg[i];
+        const size_t ni = static_cast<size_t>(1) << lg[i], done = static_cast<size_t>(1) << done_log2,
+                     rest = static_cast<size_t>(1) << rest_log2;
+        const bool to_out = in_place ? (i % 2 == 1) : ((steps - 1 - i) % 2 == 0);
+        c32 *dst = to_out ? out : scratch;
+        const ColumnPlan p{rest * done, done, ni * done, done, i + 1 < steps ? lg[i] + rest_log2 : 0};
+        if (int rc = launch_column(lg[i], src, dst, p, batch, direction, s)) return rc;
+        src = dst;
+        done_log2 += lg[i];
     }
-    const size_t n3 = static_cast<size_t>(1) << lg[2];
-    const ColumnPlan p1{n2 * n3, 1, n1, 1, log2n};
-    const ColumnPlan p2{n3 * n1, n1, n2 * n1, n1, lg[1] + lg[2]};
-    const ColumnPlan p3{n2 * n1, n2 * n1, 0, n2 * n1, 0};
-    if (in != out) {
-        if (int rc = launch_column(lg[0], in, out, p1, batch, direction, s)) return rc;       // in -> out
-        if (int rc = launch_column(lg[1], out, scratch, p2, batch, direction, s)) return rc;  // out -> scratch
-        return launch_column(lg[2], scratch, out, p3, batch, direction, s);                   // scratch -> out
-    }
-    // in place: a column pass may not overwrite its own input, so finish in scratch and copy back
-    if (int rc = launch_column(lg[0], in, scratch, p1, batch, direction, s)) return rc;
-    if (int rc = launch_column(lg[1], scratch, out, p2, batch, direction, s)) return rc;
-    if (int rc = launch_column(lg[2], out, scratch, p3, batch, direction, s)) return rc;
-    DSPGPU_HIP(hipMemcpyAsync(out, scratch, batch * n * sizeof(c32), hipMemcpyDeviceToDevice, s));
+    if (src != out) DSPGPU_HIP(hipMemcpyAsync(out, src, batch * n * sizeof(c32), hipMemcpyDeviceToDevice, s));
     return DSP_GPU_OK;
 }
 

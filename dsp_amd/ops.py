@@ -60,7 +60,7 @@ def _ptr(a):
 
 
 def fft0(x, inverse: bool = False, out=None):
-    """Batched complex FFT over the last axis (length 2^k, k in 1..24).  fft.h:31-55."""
+    """Batched complex FFT over the last axis (length 2^k, k in 1..30).  fft.h:31-55."""
     x, px, mem = _prep(x, np.complex64, "complex64")
     n = x.shape[-1]
     log2n = int(n).bit_length() - 1

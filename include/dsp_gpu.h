@@ -65,7 +65,7 @@ extern "C" {
  * `batch` independent transforms of n = 2^log2n points, fp32 instead of the
  * reference's double.  Interleaved (re,im) float pairs; transform b is at
  * in + b*2*n floats.  Natural-order output, unnormalised.  in == out is allowed.
- * 1 <= log2n <= 24.
+ * 1 <= log2n <= 30 (the reference indexes with int, fft.h:36-37: 2^30 is its own ceiling).
  */
 int dsp_gpu_fft_batch(const void *in, void *out, int log2n, size_t batch, int direction, int mem,
                       void *stream);

@@ -177,6 +177,37 @@ def test_large_single_transform_round_trip(ops, dev):
     assert abs(float(T.abs().max()) / n - 1) < 1e-3
 
 
+@pytest.mark.parametrize("log2n", [25, 26, 30])
+def test_four_pass_transforms(ops, dev, log2n):
+    """Above 2^24 points a transform takes four column passes (up to the reference's own ceiling of 2^30, its
+    int indices, fft.h:36-37): against the six-step path (different kernels and factorisation), in place, and an
+    exact-bin tone."""
+    import torch
+    from dsp_amd import dist_fft
+    n = 1 << log2n
+    g = torch.Generator(device=dev).manual_seed(log2n)
+    x = torch.view_as_complex(torch.randn(n, 2, device=dev, generator=g))
+    k = (n // 3) | 1
+    idx = torch.arange(n, device=dev, dtype=torch.int64)
+    ph = ((idx * k) % n).double() * (2 * np.pi / n)
+    x += 3.0 * torch.complex(torch.cos(ph), -torch.sin(ph)).to(torch.complex64)
+    del idx, ph
+    X = ops.fft0(x[None])[0]
+    assert int(X.abs().argmax()) == k
+    assert abs(float(X[k].abs()) / n - 3.0) < 1e-2
+    want = dist_fft.simulate([x], log2n)[0]
+    den = float(torch.linalg.vector_norm(want.view(torch.float32).double()))
+    assert float(torch.linalg.vector_norm((X - want).view(torch.float32).double())) / den <= budget(log2n)
+    del want
+    buf = x.clone()[None]
+    ops.fft0(buf, out=buf)  # in place
+    assert torch.equal(buf[0], X)
+    del buf
+    back = ops.fft0(X[None], inverse=True)[0] / n
+    err = torch.linalg.vector_norm((back - x).view(torch.float32).double()) / torch.linalg.vector_norm(x.view(torch.float32).double())
+    assert float(err) <= 2 * budget(log2n)
+
+
 def test_errors(ops, dev):
     import torch
     from dsp_amd import capi
