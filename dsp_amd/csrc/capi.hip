@@ -354,8 +354,10 @@ int dsp_gpu_iir(const float *x, float *y, size_t channels, size_t n, const doubl
     co.d0 = d0;
     if (!std::isfinite(c0) || !std::isfinite(d0)) return fail(DSP_GPU_EINVAL, "dsp_gpu_iir: non-finite c0/d0");
     const bool auto_mode = mode == DSP_GPU_IIR_AUTO;
-    if (auto_mode)  // few long channels cannot fill the chip one thread per channel
-        mode = (channels < 8192 && n >= 65536 && poles <= 8) ? DSP_GPU_IIR_SCAN : DSP_GPU_IIR_BATCH;
+    if (auto_mode)  // one lane per channel needs tens of thousands of channels to fill the chip; measured crossover on
+                    // 2^28 samples in total (scripts/iir_auto_threshold.py): 16,384 ch scan 0.53 / batch 1.08 ms,
+                    // 32,768 ch 0.67 / 0.58 ms
+        mode = (channels < 24576 && n >= 2048 && poles <= 8) ? DSP_GPU_IIR_SCAN : DSP_GPU_IIR_BATCH;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t bytes = channels * n * sizeof(float);
     if (device_overlap(x, y, bytes, mem)) {

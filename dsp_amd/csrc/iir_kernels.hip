@@ -392,9 +392,12 @@ __global__ __launch_bounds__(kSt) void iir_scan_kernel(const float *__restrict__
     // Persistent workgroups: XCD x = blockIdx.x & 7 owns the contiguous tile range [x*chunk, (x+1)*chunk) and its
     // workgroups take those tiles round-robin, loading the NEXT tile's samples into registers while the
     // current one is scanned (a tile's life was mostly waiting: SQ_WAIT_ANY 0.61 of wave cycles).
-    const unsigned chunk = (ntiles + 7u) / 8u, wgs_per_xcd = gridDim.x >> 3;
-    const unsigned t_lo = (blockIdx.x & 7u) * chunk, t_hi = min(ntiles, t_lo + chunk);
-    unsigned tile = t_lo + (blockIdx.x >> 3);
+    // (channels with only a few tiles skip the XCD map: its grid of at least 8 workgroups per channel would be
+    // mostly workgroups that exit at once, and one-wave workgroups are dispatch-rate bound)
+    const bool xcd_map = (gridDim.x & 7u) == 0 && ntiles >= 64u;
+    const unsigned chunk = xcd_map ? (ntiles + 7u) / 8u : ntiles, wgs_per_xcd = xcd_map ? gridDim.x >> 3 : gridDim.x;
+    const unsigned t_lo = xcd_map ? (blockIdx.x & 7u) * chunk : 0u, t_hi = min(ntiles, t_lo + chunk);
+    unsigned tile = t_lo + (xcd_map ? blockIdx.x >> 3 : blockIdx.x);
     if (tile >= t_hi) return;
 
     // tile geometry: samples [start, start + kTile), outputs kept from out_begin on
@@ -758,7 +761,8 @@ int scan_launch(const float *x, float *y, size_t channels, size_t n, const IirCo
     DSPGPU_HIP(hipMemcpyAsync(d_table, table.data(), table.size() * sizeof(double), hipMemcpyHostToDevice, s));
 
     // persistent: at most kScanWgsPerCu workgroups per CU of an XCD (32 CUs), fewer when there are fewer tiles
-    const dim3 grid(8u * std::min((ntiles + 7u) / 8u, 32u * kScanWgsPerCu), static_cast<unsigned>(channels));
+    const dim3 grid(ntiles >= 64u ? 8u * std::min((ntiles + 7u) / 8u, 32u * kScanWgsPerCu) : ntiles,
+                    static_cast<unsigned>(channels));
     if (fused) {
         hipLaunchKernelGGL((iir_scan_kernel<P, SCAN_FUSED, ALIGNED, WIDE>), grid, dim3(kSt), 0, s, x, y, n, co, d_table,
                            state_in, state, nullptr, nullptr, ntiles, warm, levels, d_table + 18 * ms, 0);
