@@ -229,7 +229,7 @@ constexpr int kTile = kSt * kRow;   // 4096 samples per workgroup (measured: 32-
 constexpr int kLevels = 6;          // log2(kSt)
 constexpr int kCt = 256;            // threads of the tile-carry kernel
 constexpr int kCtLevels = 8;        // log2(kCt)
-constexpr unsigned kScanWgsPerCu = 16; // resident workgroups (waves) per CU
+constexpr unsigned kScanWgsPerCu = 8;  // resident workgroups (waves) per CU: 17.5 KB of LDS each (8 and 16: 560 GSamples/s, 9: 452)
 
 enum ScanMode { SCAN_REDUCE = 0, SCAN_APPLY = 1, SCAN_FUSED = 2 };
 
