@@ -1,0 +1,95 @@
+"""Seeded random shapes through every entry point against the oracle: ragged channel counts, lengths that straddle
+tile borders, tap / window / pole counts across the kernels' internal switches.  Sizes stay small enough for the
+CPU oracle to answer in seconds."""
+import numpy as np
+import pytest
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops(dev):
+    from dsp_amd import ops as o
+    return o
+
+
+def _stable_section(rng, poles):
+    """Random stable direct form: poles inside |z| < 0.9 in conjugate pairs (plus one real pole for odd orders)."""
+    roots = []
+    for _ in range(poles // 2):
+        r, th = rng.uniform(0.2, 0.9), rng.uniform(0.1, 3.0)
+        roots += [r * np.exp(1j * th), r * np.exp(-1j * th)]
+    if poles % 2:
+        roots.append(rng.uniform(-0.9, 0.9))
+    den = np.real(np.poly(roots))            # 1 + d1 z^-1 + ...
+    b = np.concatenate([[0.0], -den[1:]])    # the reference ADDS the feedback terms
+    a = rng.standard_normal(poles + 1) * 0.5
+    return a, b
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_fft_random_shapes(ops, dev, orc, seed):
+    import torch
+    rng = np.random.default_rng(1000 + seed)
+    for _ in range(8):
+        log2n = int(rng.integers(1, 15))
+        n, batch = 1 << log2n, int(rng.integers(1, 40))
+        x = (rng.standard_normal((batch, n)) + 1j * rng.standard_normal((batch, n))).astype(np.complex64)
+        inv = bool(rng.integers(0, 2))
+        got = ops.fft0(torch.from_numpy(x).to(dev), inverse=inv).cpu().numpy()
+        want = orc.fft0(x.astype(np.complex128), inv)
+        assert rel_l2(got, want) <= 1e-5 * max(log2n, 1), (log2n, batch, inv)
+        # real wrapper with a ragged input length and zero padding
+        n_in = int(rng.integers(1, n + 1))
+        xr = rng.standard_normal((batch, n_in)).astype(np.float32)
+        nf = int(rng.integers(max(n // 2 + 1, 2), n + 1)) if n > 2 else n
+        got = ops.fft(torch.from_numpy(xr).to(dev), nf, inverse=inv).cpu().numpy()
+        for r in (0, batch - 1):
+            want = orc.fft_real(xr[r].astype(np.float64), nf, inv)
+            assert got.shape[1] == want.size and rel_l2(got[r], want) <= 1e-5 * max(log2n, 1) + 1e-7, (n_in, nf)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_fir_random_shapes(ops, dev, orc, seed):
+    import torch
+    rng = np.random.default_rng(2000 + seed)
+    for _ in range(6):
+        ntaps = int(rng.choice([1, 2, 15, 16, 17, 63, 64, 65, 255, 511, 600, int(rng.integers(1, 700))]))
+        channels, n = int(rng.integers(1, 9)), int(rng.integers(1, 30000))
+        h = rng.standard_normal(ntaps) / np.sqrt(ntaps)
+        x = rng.standard_normal((channels, n)).astype(np.float32)
+        want = orc.fir(x.astype(np.float64), h.astype(np.float32).astype(np.float64))
+        xd = torch.from_numpy(x).to(dev)
+        for mode, tol in (("direct", 1e-6), ("direct_valu", 1e-6), ("overlap_save", 1.2e-4), ("auto", 1.2e-4)):
+            got = ops.convolve(xd, h, mode=mode).cpu().numpy()
+            assert rel_l2(got, want) <= tol, (mode, ntaps, channels, n)
+        npts = int(rng.integers(1, min(n, 3000) + 1))
+        got = ops.moving_average(xd, npts).cpu().numpy()
+        assert rel_l2(got, orc.moving_average(x.astype(np.float64), npts)) <= 2e-6, (npts, n)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_iir_random_shapes(ops, dev, orc, seed):
+    import torch
+    rng = np.random.default_rng(3000 + seed)
+    for _ in range(6):
+        poles = int(rng.integers(1, 9))
+        a, b = _stable_section(rng, poles)
+        c0, d0 = (1.0, 0.0) if rng.integers(0, 2) else (float(rng.uniform(-2, 2)), float(rng.uniform(-1, 1)))
+        channels, n = int(rng.integers(1, 200)), int(rng.integers(1, 12000))
+        x = rng.standard_normal((channels, n)).astype(np.float32)
+        st0 = rng.standard_normal((channels, 2 * poles)) * 0.3
+        st0[:, :poles] = st0[:, :poles].astype(np.float32)
+        so = np.zeros((channels, 2 * (poles + 1)))
+        so[:, 1:poles + 1] = st0[:, :poles]
+        so[:, poles + 2:] = st0[:, poles:]
+        want = orc.iir(x.astype(np.float64), a, b, c0, d0, state=so)
+        for mode in ("batch", "scan", "auto"):
+            st = torch.from_numpy(st0.copy()).to(dev)
+            got = ops.iir(torch.from_numpy(x).to(dev), a, b, c0, d0, state=st, mode=mode).cpu().numpy()
+            assert rel_l2(got, want) <= 2e-6, (mode, poles, channels, n)
+            g = st.cpu().numpy()
+            assert np.allclose(g[:, :poles], so[:, 1:poles + 1])
+            assert np.allclose(g[:, poles:], so[:, poles + 2:], rtol=1e-6, atol=1e-9), (mode, poles, channels, n)
