@@ -151,6 +151,9 @@ struct ColumnPlan {
     size_t out_a = 0;     // output stride of a                                  (default L*B)
     size_t out_hi = 0;    // natural-order store: k -> (k >> out_split)*out_hi + (k & (2^out_split - 1))*s_k
     int out_split = 0;
+    // first pass of a large real-input transform (dsp::fft, fft.h:57-83): `in` is really float rows of real_n_in
+    // samples (row stride real_stride); element (a, l, b) = sample l*B + b of row a, zero beyond real_n_in
+    size_t real_n_in = 0, real_stride = 0;
 };
 
 template <int R, int NS, int LOG2L, int C>
@@ -189,7 +192,14 @@ __global__ __launch_bounds__(TH) void fft_column_kernel(const c32 *__restrict__ 
     const c32 *src = in + a * (plan.in_a ? plan.in_a : L * plan.B) + b;
 
     c32 r[kPoints];
-    if (plan.in_hi) {
+    if (plan.real_stride) {
+        const float *row = reinterpret_cast<const float *>(in) + a * plan.real_stride;
+#pragma unroll
+        for (int m = 0; m < kPoints; ++m) {
+            const size_t i = static_cast<size_t>(lt + T * m) * plan.B + b;
+            r[m] = mk(i < plan.real_n_in ? row[i] : 0.0f, 0.0f);
+        }
+    } else if (plan.in_hi) {
         const unsigned mask = (1u << plan.in_split) - 1u;
 #pragma unroll
         for (int m = 0; m < kPoints; ++m) {
@@ -270,16 +280,6 @@ __global__ __launch_bounds__(TH) void fft_column_kernel(const c32 *__restrict__ 
     for (int m = 0; m < kPoints; ++m) {
         const unsigned k = lt + T * m;
         dst[static_cast<size_t>(k) * plan.s_k] = r[m];
-    }
-}
-
-// real rows -> zero padded complex rows (front end of the large real-input path)
-__global__ __launch_bounds__(kThreads) void pack_real_kernel(const float *__restrict__ in, c32 *__restrict__ out,
-                                                             size_t n_in, size_t in_stride, size_t n, size_t total) {
-    for (size_t i = static_cast<size_t>(blockIdx.x) * kThreads + threadIdx.x; i < total;
-         i += static_cast<size_t>(gridDim.x) * kThreads) {
-        const size_t row = i / n, col = i % n;
-        out[i] = mk(col < n_in ? in[row * in_stride + col] : 0.0f, 0.0f);
     }
 }
 
@@ -369,7 +369,8 @@ int launch_column(int log2l, const c32 *in, c32 *out, const ColumnPlan &plan, si
 // n_i, multiplies by W_{n_i * rest}^{k_i * r} (r = the index into n_{i+1} .. n_K, rest = their product; nothing on
 // the last step) and stores [n_{i+1} .. n_K][k_i][k_{i-1} .. k_1] -- after step K that is natural order.  The
 // passes ping-pong between `out` and one scratch buffer so that the input is never modified.
-int launch_large(const c32 *in, c32 *out, int log2n, size_t batch, int direction, hipStream_t s) {
+int launch_large(const c32 *in, c32 *out, int log2n, size_t batch, int direction, hipStream_t s,
+                 const float *real_in = nullptr, size_t real_n_in = 0, size_t real_stride = 0) {
     const size_t n = static_cast<size_t>(1) << log2n;
     const int steps = log2n <= 16 ? 2 : (log2n <= 24 ? 3 : 4);
     int lg[4] = {0, 0, 0, 0};
@@ -382,8 +383,8 @@ int launch_large(const c32 *in, c32 *out, int log2n, size_t batch, int direction
     c32 *scratch = static_cast<c32 *>(scratch_v);
     // destination of pass i: the last one writes `out` and they alternate backwards; in place, the first pass
     // may not write what it reads, so the chain starts in scratch and a copy finishes it if it ends there
-    const bool in_place = in == out;
-    const c32 *src = in;
+    const bool in_place = in == out && !real_in;
+    const c32 *src = real_in ? reinterpret_cast<const c32 *>(real_in) : in;
     int done_log2 = 0, rest_log2 = log2n;
     for (int i = 0; i < steps; ++i) {
         rest_log2 -= lg[i];
@@ -391,7 +392,11 @@ int launch_large(const c32 *in, c32 *out, int log2n, size_t batch, int direction
                      rest = static_cast<size_t>(1) << rest_log2;
         const bool to_out = in_place ? (i % 2 == 1) : ((steps - 1 - i) % 2 == 0);
         c32 *dst = to_out ? out : scratch;
-        const ColumnPlan p{rest * done, done, ni * done, done, i + 1 < steps ? lg[i] + rest_log2 : 0};
+        ColumnPlan p{rest * done, done, ni * done, done, i + 1 < steps ? lg[i] + rest_log2 : 0};
+        if (i == 0 && real_in) {  // the real -> complex packing rides the first pass's loads
+            p.real_n_in = real_n_in;
+            p.real_stride = real_stride;
+        }
         if (int rc = launch_column(lg[i], src, dst, p, batch, direction, s)) return rc;
         src = dst;
         done_log2 += lg[i];
@@ -486,13 +491,8 @@ int launch_fft_real_batch(const float *in, size_t n_in, size_t in_stride, float2
     }
     const size_t n = static_cast<size_t>(1) << log2n;
     const size_t total = batch * n;
-    void *packed_v = nullptr;
-    if (int rc = workspace(WS_SCRATCH_B, total * sizeof(c32), &packed_v)) return rc;
-    c32 *packed = static_cast<c32 *>(packed_v);
     const unsigned grid = static_cast<unsigned>(std::min<size_t>((total + kThreads - 1) / kThreads, 2048 * 8));
-    hipLaunchKernelGGL(pack_real_kernel, dim3(grid), dim3(kThreads), 0, s, in, packed, n_in, in_stride, n, total);
-    if (int rc = check_launch("pack_real_kernel")) return rc;
-    if (int rc = launch_large(packed, out, log2n, batch, direction, s)) return rc;
+    if (int rc = launch_large(nullptr, out, log2n, batch, direction, s, in, n_in, in_stride)) return rc;
     if (!shifted) return DSP_GPU_OK;
     hipLaunchKernelGGL(swap_halves_kernel, dim3(grid), dim3(kThreads), 0, s, out, n, total / 2);
     return check_launch("swap_halves_kernel");
