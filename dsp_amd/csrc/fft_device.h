@@ -223,7 +223,15 @@ DSP_DEV void stockham_pass(c32 (&r)[P], int lt) {
             constexpr int LOG2DEN = __builtin_ctz(NS * R);
             const unsigned k = static_cast<unsigned>(lt + T * s) & (NS - 1);
             c32 pw[R];
-            pw[1] = unit_root<SIGN>(k, LOG2DEN);
+            if constexpr (B > 1 && NS * R == N) {
+                // last pass, several butterflies per thread: k_s = k_0 + T*s never wraps (lt < T, T*B = NS), and
+                // T*s / N = s/16, so W_N^{k_s} = W_N^{k_0} * W_16^s with W_16^s a compile-time constant: one sincospif
+                // per thread instead of one per butterfly
+                const c32 w0 = unit_root<SIGN>(static_cast<unsigned>(lt) & (NS - 1), LOG2DEN);
+                pw[1] = s == 0 ? w0 : cmul(w0, c32{cos16(s), SIGN * sin16(s)});
+            } else {
+                pw[1] = unit_root<SIGN>(k, LOG2DEN);
+            }
 #pragma unroll
             for (int t = 2; t < R; ++t) pw[t] = cmul(pw[t >> 1], pw[t - (t >> 1)]);
 #pragma unroll
