@@ -184,7 +184,9 @@ __global__ __launch_bounds__(TH) void fft_column_kernel(const c32 *__restrict__ 
     const int tid = threadIdx.x;
     const int c = tid % C;
     const int lt = tid / C;
-    const size_t tile = blockIdx.x;                       // tiles never straddle an `a` slab: B % C == 0
+    const size_t ntile = gridDim.x;
+    const size_t chunkx = (ntile + 7) / 8;
+    const size_t tile = (ntile & 7) == 0 ? xcd_tile(blockIdx.x, chunkx) : blockIdx.x;  // tiles never straddle an `a` slab: B % C == 0
     const size_t tiles_per_a = columns_per_a / C;
     const size_t a = tile / tiles_per_a;
     const size_t b = (tile % tiles_per_a) * C + c;
@@ -204,11 +206,11 @@ __global__ __launch_bounds__(TH) void fft_column_kernel(const c32 *__restrict__ 
 #pragma unroll
         for (int m = 0; m < kPoints; ++m) {
             const unsigned l = lt + T * m;
-            r[m] = src[static_cast<size_t>(l >> plan.in_split) * plan.in_hi + static_cast<size_t>(l & mask) * in_lo];
+            r[m] = load_stream(src + static_cast<size_t>(l >> plan.in_split) * plan.in_hi + static_cast<size_t>(l & mask) * in_lo);
         }
     } else {
 #pragma unroll
-        for (int m = 0; m < kPoints; ++m) r[m] = src[static_cast<size_t>(lt + T * m) * in_lo];
+        for (int m = 0; m < kPoints; ++m) r[m] = load_stream(src + static_cast<size_t>(lt + T * m) * in_lo);
     }
     if (plan.in_tw_log2 > 0) {
         // W^{k1 * n2}, n2 = (lt + T*m)*B + b:  W^{k1*(lt*B + b)} * (W^{k1*T*B})^m, the two roots from exact
@@ -272,14 +274,14 @@ __global__ __launch_bounds__(TH) void fft_column_kernel(const c32 *__restrict__ 
 #pragma unroll
         for (int m = 0; m < kPoints; ++m) {
             const unsigned k = lt + T * m;
-            dst[static_cast<size_t>(k >> plan.out_split) * plan.out_hi + static_cast<size_t>(k & mask) * plan.s_k] = r[m];
+            store_stream(dst + static_cast<size_t>(k >> plan.out_split) * plan.out_hi + static_cast<size_t>(k & mask) * plan.s_k, r[m]);
         }
         return;
     }
 #pragma unroll
     for (int m = 0; m < kPoints; ++m) {
         const unsigned k = lt + T * m;
-        dst[static_cast<size_t>(k) * plan.s_k] = r[m];
+        store_stream(dst + static_cast<size_t>(k) * plan.s_k, r[m]);
     }
 }
 
