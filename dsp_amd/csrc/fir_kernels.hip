@@ -378,7 +378,11 @@ __global__ __launch_bounds__(kThreads) void moving_average_kernel(const float *_
     const long long nn = static_cast<long long>(n);
     const long long mid = npoints / 2;
     const int window = 2 * static_cast<int>(mid) + 1;
-    const long long out0 = static_cast<long long>(blockIdx.x) * kMaTile;  // first output of the tile
+    // XCD-contiguous tiles along the channel (workgroups x and x + 8 share an XCD).  Worth 1 %; plain (cached) loads
+    // would let the neighbouring tile's window halo come out of L2 (traffic 8.55 -> 8.01 GiB) but run 3 % slower
+    // than streaming loads
+    const unsigned bx = (gridDim.x & 7u) == 0 ? (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+    const long long out0 = static_cast<long long>(bx) * kMaTile;  // first output of the tile
     const long long first = out0 - mid;                                   // first sample the tile needs
     const long long seg0 = first & ~3ll;                                  // staged from here (16-byte aligned)
     const int shift = static_cast<int>(first - seg0);                     // 0..3
