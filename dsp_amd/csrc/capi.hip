@@ -27,6 +27,10 @@ struct Buffer {
     size_t bytes = 0;
 };
 
+constexpr size_t kTapCacheEntries = 256;      // a partitioned filter caches one entry per segment
+constexpr int kSegmentTaps = 2048;            // taps per overlap-save pass of a partitioned filter
+constexpr int kMaxPartitionedTaps = 1 << 18;  // 128 passes
+
 struct TapEntry {  // uploaded tap set (+ lazily built overlap-save spectrum)
     std::vector<float> taps;
     float *d_taps = nullptr;
@@ -60,7 +64,7 @@ int cached_taps(const float *taps, int ntaps, bool want_spectrum, hipStream_t s,
             break;
         }
     if (!hit) {
-        if (st.taps.size() >= 64) {  // bounded cache: drop everything when full
+        if (st.taps.size() >= kTapCacheEntries) {  // bounded cache: drop everything when full
             DSPGPU_HIP(hipDeviceSynchronize());
             for (TapEntry &e : st.taps) {
                 if (e.d_taps) (void)hipFree(e.d_taps);
@@ -78,7 +82,7 @@ int cached_taps(const float *taps, int ntaps, bool want_spectrum, hipStream_t s,
             (void)hipFree(e.d_taps);
             return fail(DSP_GPU_EHIP, "tap upload failed: %s", hipGetErrorString(ce));
         }
-        st.taps.reserve(64);
+        st.taps.reserve(kTapCacheEntries);
         st.taps.push_back(std::move(e));
         hit = &st.taps.back();
     }
@@ -249,14 +253,18 @@ static bool device_overlap(const void *a, const void *b, size_t bytes, int mem) 
 static int convolve_impl(const char *who, const float *x, float *y, size_t channels, size_t n, const float *taps,
                          int ntaps, float *history, unsigned long long position, int mode, int mem, void *stream) {
     if (!x || !y || !taps) return fail(DSP_GPU_EINVAL, "%s: null buffer", who);
-    if (ntaps < 1 || ntaps > 4096) return fail(DSP_GPU_EINVAL, "%s: ntaps %d outside [1,4096]", who, ntaps);
     if (mode != DSP_GPU_CONV_AUTO && mode != DSP_GPU_CONV_DIRECT && mode != DSP_GPU_CONV_OVERLAP_SAVE &&
         mode != DSP_GPU_CONV_DIRECT_VALU)
         return fail(DSP_GPU_EINVAL, "%s: mode %d", who, mode);
     if (mode == DSP_GPU_CONV_DIRECT_VALU && history)
         return fail(DSP_GPU_EUNSUPPORTED, "%s: the VALU direct form has no streaming variant", who);
-    if (mode == DSP_GPU_CONV_OVERLAP_SAVE && ntaps > 2049)
-        return fail(DSP_GPU_EINVAL, "%s: overlap-save supports at most 2049 taps, got %d", who, ntaps);
+    // one 4096-point block holds 2049 taps; longer filters run partitioned (2048-tap segments, one overlap-save
+    // pass each, accumulated) in the one-shot form
+    const bool partitioned = ntaps > 2049 && !history &&
+                             (mode == DSP_GPU_CONV_OVERLAP_SAVE || (mode == DSP_GPU_CONV_AUTO && (ntaps > 4096 || n >= 4096)));
+    const int max_taps = partitioned ? kMaxPartitionedTaps : (mode == DSP_GPU_CONV_OVERLAP_SAVE ? 2049 : 4096);
+    if (ntaps < 1 || ntaps > max_taps)
+        return fail(DSP_GPU_EINVAL, "%s: ntaps %d outside [1,%d] for this mode", who, ntaps, max_taps);
     if (bad_mem(mem)) return fail(DSP_GPU_EINVAL, "%s: mem %d", who, mem);
     if (channels == 0 || n == 0) return DSP_GPU_OK;
     if (device_overlap(x, y, channels * n * sizeof(float), mem))
@@ -264,9 +272,31 @@ static int convolve_impl(const char *who, const float *x, float *y, size_t chann
     if (mode == DSP_GPU_CONV_AUTO)  // long filters on long signals amortise the FFT blocks
         mode = (ntaps >= 64 && ntaps <= 2049 && n >= 4096) ? DSP_GPU_CONV_OVERLAP_SAVE : DSP_GPU_CONV_DIRECT;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t bytes = channels * n * sizeof(float);
+    if (partitioned) {
+        const float *dx = x;
+        float *dy = y;
+        HostStage hs;
+        if (mem == DSP_GPU_MEM_HOST) {
+            if (int rc = stage_in(x, bytes, bytes, s, &hs)) return rc;
+            dx = static_cast<const float *>(hs.d_in);
+            dy = static_cast<float *>(hs.d_out);
+        }
+        for (int seg0 = 0; seg0 < ntaps; seg0 += kSegmentTaps) {
+            const int len = std::min(kSegmentTaps, ntaps - seg0);
+            TapEntry *seg = nullptr;
+            if (int rc = cached_taps(taps + seg0, len, true, s, &seg)) return rc;
+            if (int rc = launch_fir_os_segment(dx, dy, channels, n, seg->d_spectrum, len, static_cast<size_t>(seg0),
+                                               seg0 > 0, s))
+                return rc;
+        }
+        // filter.h:126,133: outputs without a full window behind them stay zero
+        const size_t head = std::min<size_t>(n, static_cast<size_t>(ntaps - 1));
+        if (head) DSPGPU_HIP(hipMemset2DAsync(dy, n * sizeof(float), 0, head * sizeof(float), channels, s));
+        return mem == DSP_GPU_MEM_HOST ? stage_out(y, bytes, s, hs) : DSP_GPU_OK;
+    }
     TapEntry *te = nullptr;
     if (int rc = cached_taps(taps, ntaps, mode == DSP_GPU_CONV_OVERLAP_SAVE, s, &te)) return rc;
-    const size_t bytes = channels * n * sizeof(float);
     const size_t hist_bytes = channels * static_cast<size_t>(ntaps - 1) * sizeof(float);
     const float *dx = x;
     float *dy = y;

@@ -264,10 +264,21 @@ constexpr int kOsLog2N = 12;
 
 // hspec: FORWARD spectrum of the zero padded taps (unscaled).  Block b of a channel produces
 // outputs [order + b*L, order + (b+1)*L) from inputs [b*L, b*L + 4096), L = 4096 - order.
+// `ex` serves the partitioned form for filters longer than one block allows (launch_fir_partitioned): the rows
+// of x and y are `stride` apart while only n samples of each take part, outputs land `yoff` samples further on and
+// are ADDED to what is there, and the history in front of x is all zeros without a buffer to prove it.
+struct OsExtra {
+    size_t stride;   // distance between channels in x and y (n in the plain forms)
+    size_t yoff;     // output j is stored at y[ch*stride + yoff + j]
+    int accumulate;  // y += result instead of y = result
+    int zero_hist;   // streaming form over an all-zero history (no `hist` buffer)
+};
+
 __global__ __launch_bounds__(kThreads) void fir_overlap_save_kernel(const float *__restrict__ x, float *__restrict__ y,
                                                                     size_t n, const c32 *__restrict__ hspec, int ntaps,
                                                                     unsigned pairs_per_channel, size_t tiles, size_t chunk,
-                                                                    const float *__restrict__ hist, int zero_head) {
+                                                                    const float *__restrict__ hist, int zero_head,
+                                                                    OsExtra ex) {
     __shared__ c32 lds[kLdsElems];
     const int tid = threadIdx.x;
     const size_t tile = xcd_tile_of(blockIdx.x, chunk);  // each XCD streams a contiguous range of block pairs
@@ -278,10 +289,10 @@ __global__ __launch_bounds__(kThreads) void fir_overlap_save_kernel(const float 
     const long long L = kOsN - order;
     // streaming form: the blocks run over the virtual signal history ++ x (hoff = ntaps-1 samples of
     // history in front), so every output of x is kept; one-shot form: hoff = 0 and y[0, order) = 0
-    const long long hoff = hist ? order : 0;
+    const long long hoff = (hist || ex.zero_hist) ? order : 0;
     const long long nn = static_cast<long long>(n) + hoff;
-    const float *xc = x + ch * n - hoff;       // xc[v] valid for v >= hoff
-    float *yc = y + ch * n - hoff;
+    const float *xc = x + ch * ex.stride - hoff;       // xc[v] valid for v >= hoff
+    float *yc = y + ch * ex.stride + ex.yoff - hoff;
     const float *hc = hist ? hist + ch * order : nullptr;
     const long long in_a = static_cast<long long>(2 * pair) * L, in_b = in_a + L;
 
@@ -298,8 +309,8 @@ __global__ __launch_bounds__(kThreads) void fir_overlap_save_kernel(const float 
 #pragma unroll
         for (int m = 0; m < kPoints; ++m) {
             const long long ia = in_a + tid + kThreads * m, ib = in_b + tid + kThreads * m;
-            const float va = ia >= nn ? 0.0f : (ia >= hoff ? __builtin_nontemporal_load(xc + ia) : hc[ia]);
-            const float vb = ib >= nn ? 0.0f : (ib >= hoff ? __builtin_nontemporal_load(xc + ib) : hc[ib]);
+            const float va = ia >= nn ? 0.0f : (ia >= hoff ? __builtin_nontemporal_load(xc + ia) : (hc ? hc[ia] : 0.0f));
+            const float vb = ib >= nn ? 0.0f : (ib >= hoff ? __builtin_nontemporal_load(xc + ib) : (hc ? hc[ib] : 0.0f));
             r[m] = mk(va, vb);
         }
     }
@@ -314,8 +325,19 @@ __global__ __launch_bounds__(kThreads) void fir_overlap_save_kernel(const float 
     __syncthreads();  // the forward passes' last LDS image has been read by everyone
     fft_passes<kOsLog2N, -1>(r, lds, tid, 0);
 
-    if (pair == 0 && !hist)  // filter.h:126,133: the first `order` outputs of the channel stay zero
+    if (pair == 0 && hoff == 0)  // filter.h:126,133: the first `order` outputs of the channel stay zero
         for (long long j = tid; j < order && j < nn; j += kThreads) yc[j] = 0.0f;
+    if (ex.accumulate) {  // partitioned form: this segment's contribution on top of the earlier ones
+#pragma unroll
+        for (int m = 0; m < kPoints; ++m) {
+            const long long k = tid + kThreads * m;
+            if (k < order) continue;
+            const long long ja = in_a + k, jb = in_b + k;
+            if (ja < nn) yc[ja] += r[m].x;
+            if (jb < nn) yc[jb] += r[m].y;
+        }
+        return;
+    }
     if (interior) {  // every kept output is in range and past the zero head
         float *pa = yc + in_a + tid, *pb = pa + L;
         const int ord = static_cast<int>(order);
@@ -539,12 +561,12 @@ int launch_fir_spectrum(const float *d_taps, int ntaps, float2 *d_hspec_f2, hipS
                                  DSP_GPU_FORWARD, 0, s);
 }
 
-int launch_fir_overlap_save(const float *x, float *y, size_t channels, size_t n, const float2 *d_hspec_f2, int ntaps,
-                            const float *hist, int zero_head, hipStream_t s) {
-    const c32 *d_hspec = reinterpret_cast<const c32 *>(d_hspec_f2);
+namespace {
+int launch_os(const float *x, float *y, size_t channels, size_t n, const c32 *d_hspec, int ntaps, const float *hist,
+              int zero_head, const OsExtra &ex, hipStream_t s) {
     const long long order = ntaps - 1;
     const long long L = kOsN - order;
-    const long long nv = static_cast<long long>(n) + (hist ? order : 0);  // length of the (virtual) signal
+    const long long nv = static_cast<long long>(n) + ((hist || ex.zero_hist) ? order : 0);  // length of the (virtual) signal
     const long long valid = nv > order ? nv - order : 0;
     long long nblocks = (valid + L - 1) / L;
     if (nblocks < 1) nblocks = 1;  // block 0 also zero-fills y[0, order)
@@ -553,8 +575,24 @@ int launch_fir_overlap_save(const float *x, float *y, size_t channels, size_t n,
     const size_t chunk = (tiles + 7) / 8;
     if (8 * chunk > 0x7fffffffull) return fail(DSP_GPU_EUNSUPPORTED, "overlap-save FIR: grid too large");
     hipLaunchKernelGGL(fir_overlap_save_kernel, dim3(static_cast<unsigned>(8 * chunk)), dim3(kThreads), 0, s, x, y, n,
-                       d_hspec, ntaps, pairs, tiles, chunk, hist, zero_head);
+                       d_hspec, ntaps, pairs, tiles, chunk, hist, zero_head, ex);
     return check_launch("fir_overlap_save_kernel");
+}
+}  // namespace
+
+int launch_fir_overlap_save(const float *x, float *y, size_t channels, size_t n, const float2 *d_hspec_f2, int ntaps,
+                            const float *hist, int zero_head, hipStream_t s) {
+    return launch_os(x, y, channels, n, reinterpret_cast<const c32 *>(d_hspec_f2), ntaps, hist, zero_head,
+                     OsExtra{n, 0, 0, 0}, s);
+}
+
+// One segment of a partitioned long filter (taps [seg0, seg0 + seg_len) of it): y[.][seg0 + j] (+)= sum_i h_seg[i] x[.][j - i]
+// for j < n - seg0, every output kept (the samples before x[0] are zeros).
+int launch_fir_os_segment(const float *x, float *y, size_t channels, size_t n, const float2 *d_hspec_f2, int seg_len,
+                          size_t seg0, int accumulate, hipStream_t s) {
+    if (seg0 >= n) return DSP_GPU_OK;
+    return launch_os(x, y, channels, n - seg0, reinterpret_cast<const c32 *>(d_hspec_f2), seg_len, nullptr, 0,
+                     OsExtra{n, seg0, accumulate, 1}, s);
 }
 
 int launch_moving_average(const float *x, float *y, size_t channels, size_t n, int npoints, hipStream_t s) {

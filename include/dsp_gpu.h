@@ -87,7 +87,9 @@ int dsp_gpu_fft_real_batch(const float *in, size_t n_in, size_t in_stride, void 
  * y[ch][j] = sum_{i<ntaps} x[ch][j-i]*taps[i] for j >= ntaps-1 and 0 before that
  * (filter.h:133 -- causal, first ntaps-1 outputs zero).  `taps` is a HOST pointer to
  * ntaps floats shared by all channels (e.g. the fp32 cast of dsp::sinc, dsp.h:47-79).
- * 1 <= ntaps <= 4096 (direct), ntaps <= 2049 (overlap-save).  Device buffers x and y must not overlap
+ * 1 <= ntaps <= 4096 (direct); overlap-save holds 2049 taps per 4096-point block and runs longer filters
+ * partitioned -- 2048-tap segments, one pass each, accumulated -- up to 262,144 taps (AUTO does the same above 2049
+ * taps).  Device buffers x and y must not overlap
  * (DSP_GPU_EINVAL); host buffers are staged and may.
  */
 int dsp_gpu_convolve(const float *x, float *y, size_t channels, size_t n, const float *taps,

@@ -43,7 +43,8 @@ def test_argument_errors_without_a_gpu():
     assert L.dsp_gpu_fft_batch(p, p, 2, 1, 7, 1, None) == capi.EINVAL
     assert L.dsp_gpu_fft_batch(p, p, 2, 0, 0, 1, None) == capi.OK  # empty batch is a no-op
     assert L.dsp_gpu_convolve(p, p, 1, 8, p, 0, 0, 1, None) == capi.EINVAL
-    assert L.dsp_gpu_convolve(p, p, 1, 8, p, 3000, capi.CONV_OVERLAP_SAVE, 1, None) == capi.EINVAL
+    assert L.dsp_gpu_convolve(p, p, 1, 8, p, (1 << 18) + 1, capi.CONV_OVERLAP_SAVE, 1, None) == capi.EINVAL
+    assert L.dsp_gpu_convolve(p, p, 1, 8, p, 5000, capi.CONV_DIRECT, 1, None) == capi.EINVAL
     assert L.dsp_gpu_convolve(p, p, 0, 8, p, 3, 0, 1, None) == capi.OK
     assert L.dsp_gpu_moving_average(p, p, 1, 4, 5, 1, None) == capi.EINVAL  # n < npoints
     assert L.dsp_gpu_iir(p, p, 1, 8, p, p, 0, 1.0, 0.0, None, 0, 1, None) == capi.EINVAL

@@ -174,7 +174,9 @@ def test_errors(ops, dev):
     from dsp_amd import capi
     x = torch.zeros(2, 100, device=dev)
     with pytest.raises(capi.DspGpuError):
-        ops.convolve(x, np.zeros(3000), "overlap_save")
+        ops.convolve(x, np.zeros((1 << 18) + 1), "overlap_save")  # beyond the partitioned limit
+    with pytest.raises(capi.DspGpuError):  # no streaming variant of the partitioned form
+        ops.convolve_stream(x, np.zeros(3000), torch.zeros(2, 2999, device=dev), 0, mode="overlap_save")
     with pytest.raises(capi.DspGpuError):
         ops.convolve(x, np.zeros(5000), "direct")
     with pytest.raises(capi.DspGpuError):
@@ -258,3 +260,33 @@ def _state_after(ops, xd, a, b):
     st = torch.zeros(xd.shape[0], 4, dtype=torch.float64, device=xd.device)
     ops.iir(xd, a, b, state=st, mode="batch")
     return st
+
+
+# ---- filters longer than one overlap-save block: partitioned ------------------------------------------
+@pytest.mark.parametrize("ntaps,channels,n", [(2050, 2, 20000), (4097, 2, 16000), (6000, 1, 25000), (10001, 2, 12000),
+                                              (5000, 1, 3000), (3000, 2, 2500)])
+def test_partitioned_long_filters(ops, dev, orc, ntaps, channels, n):
+    """More taps than a 4096-point block holds (2049): 2048-tap segments, one overlap-save pass each, accumulated;
+    the first ntaps-1 outputs stay zero as ever (filter.h:126,133).  Against the reference's direct loop."""
+    import torch
+    from dsp_amd import capi
+    rng = np.random.default_rng(ntaps)
+    h = (rng.standard_normal(ntaps) * np.exp(-np.arange(ntaps) / (ntaps / 4))).astype(np.float32)  # a decaying response
+    x = rng.standard_normal((channels, n)).astype(np.float32)
+    want = orc.fir(x.astype(np.float64), h.astype(np.float64))
+    xd = torch.from_numpy(x).to(dev)
+    guard = torch.full((channels + 2, n), 3.0, device=dev)
+    ops.convolve(xd, h, mode="overlap_save", out=guard[1:-1])
+    g = guard.cpu().numpy()
+    assert (g[0] == 3).all() and (g[-1] == 3).all()
+    assert rel_l2(g[1:-1], want) <= OS_TOL
+    assert not g[1:-1][:, : min(n, ntaps - 1)].any()
+    assert np.array_equal(ops.convolve(x, h, mode="overlap_save"), g[1:-1])       # host pointers
+    if ntaps <= 4096:
+        assert rel_l2(ops.convolve(xd, h, mode="direct").cpu().numpy(), want) <= DIRECT_TOL
+        auto = ops.convolve(xd, h, mode="auto").cpu().numpy()                       # AUTO: partitioned from 4096 samples up
+        assert rel_l2(auto, want) <= OS_TOL
+    else:
+        assert np.array_equal(ops.convolve(xd, h, mode="auto").cpu().numpy(), g[1:-1])
+        with pytest.raises(capi.DspGpuError):
+            ops.convolve(xd, h, mode="direct")
