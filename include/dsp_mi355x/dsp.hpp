@@ -257,6 +257,8 @@ struct SincFilter {
     // mode: DSP_GPU_CONV_AUTO / DIRECT / OVERLAP_SAVE; `channels` rows share the kernel
     template <typename Buffer>
     Buffer apply(const Buffer &sampleBuffer, size_t channels = 1, int mode = DSP_GPU_CONV_DIRECT) const {
+        // the direct form stops at 4096 taps; longer kernels go through the (partitioned) overlap-save path
+        if (mode == DSP_GPU_CONV_DIRECT && m_taps.size() > 4096) mode = DSP_GPU_CONV_OVERLAP_SAVE;
         return detail::fir(sampleBuffer, m_taps, mode, channels);
     }
     std::vector<double> kernel() const { return m_kernel; }
