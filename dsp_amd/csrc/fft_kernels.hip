@@ -10,12 +10,15 @@
 //                              HBM traffic is exactly one coalesced 8 B read and one 8 B write
 //                              per point: 16 B/sample, the figure the roofline is quoted on.
 //   fft_tiny_kernel<LOG2N>     log2n <= 3: one thread per transform, registers only.
-//   fft_column_kernel<LOG2L>   building block of large transforms (13 <= log2n <= 24): FFTs of
-//                              length L <= 256 down the middle axis of an [A][L][B] view, 16
-//                              adjacent columns per workgroup so every global access is a 128 B
-//                              run; fuses the inter-step twiddle and the transposed store.  A
-//                              transform of 2^13..2^16 points takes two such passes, 2^17..2^24
-//                              three (the classic four-/six-step decomposition, all on one GPU).
+//   fft_column_kernel<LOG2L>   building block of large transforms (13 <= log2n <= 30): FFTs of
+//                              length L <= 256 down the middle axis of an [A][L][B] view, 32-64
+//                              adjacent columns per workgroup (256-512 byte runs), XCD-contiguous
+//                              tile order, streaming accesses; fuses the inter-step twiddle and the
+//                              transposed store (staged through LDS so a wave writes 512 contiguous
+//                              bytes), optionally the real -> complex packing of dsp::fft on the first
+//                              pass and the per-rank block layouts of the distributed transform
+//                              (ColumnPlan).  A transform of 2^13..2^16 points takes two such passes,
+//                              2^17..2^24 three, 2^25..2^30 four, all on one GPU.
 #include <algorithm>
 
 #include "common.h"

@@ -17,6 +17,11 @@
 //                            (a + i b; valid because the taps are real), multiplied by the cached
 //                            tap spectrum, inverse FFT, real/imag parts stored.  One workgroup per
 //                            block pair, the transform never leaves registers + LDS.
+//                            Streaming (carried input tail) and partitioned (filters longer than one
+//                            block, OsExtra) forms share the kernel.
+//   fir_direct_valu_kernel   the direct form on the vector ALU (packed fp32, sliding register window):
+//                            the matrix-core kernel's measured A/B partner, not picked by AUTO.
+//   fir_history_kernel       new input tail for the streaming form.
 //   moving_average_kernel    windows summed from 16-sample partial sums held in LDS (no running
 //                            sum along the signal, so no accumulated drift).
 #include <algorithm>
