@@ -10,6 +10,9 @@
 //                              HBM traffic is exactly one coalesced 8 B read and one 8 B write
 //                              per point: 16 B/sample, the figure the roofline is quoted on.
 //   fft_tiny_kernel<LOG2N>     log2n <= 3: one thread per transform, registers only.
+//   fft_big_kernel<LOG2N>      log2n = 13, 14: the whole transform in one workgroup's LDS (N/16 threads, 70 / 139 KB),
+//                              four radix passes, still a single 16 B/sample trip through HBM; persistent
+//                              workgroups that prefetch the next transform.
 //   fft_column_kernel<LOG2L>   building block of large transforms (13 <= log2n <= 30): FFTs of
 //                              length L <= 256 down the middle axis of an [A][L][B] view, 32-64
 //                              adjacent columns per workgroup (256-512 byte runs), XCD-contiguous
@@ -106,6 +109,39 @@ __global__ __launch_bounds__(kThreads) void fft_lds_kernel(const void *__restric
             if constexpr (SHIFTED) k = (k + N / 2) & (N - 1);
             store_stream(dst + k, r[m]);
         }
+    }
+}
+
+// 2^13 and 2^14 points in ONE pass through HBM: a workgroup of N/16 threads holds the whole transform in LDS
+// (70 / 139 KB: two / one workgroup per CU), four radix passes, three exchanges.  With so few workgroups per CU
+// nothing else hides the loads, so the workgroups are persistent and fetch the next transform into registers while
+// the current one is transformed.  XCD x owns the contiguous range [x*chunk, (x+1)*chunk) of the batch.
+template <int LOG2N, int SIGN>
+__global__ __launch_bounds__((1 << LOG2N) / kPoints) void fft_big_kernel(const c32 *__restrict__ in, c32 *__restrict__ out,
+                                                                         size_t batch, size_t chunk) {
+    constexpr int N = 1 << LOG2N;
+    constexpr int T = N / kPoints;  // threads
+    extern __shared__ __attribute__((aligned(16))) c32 big_lds[];
+    const int lt = threadIdx.x;
+    const size_t per_xcd = gridDim.x >> 3;
+    const size_t lo = static_cast<size_t>(blockIdx.x & 7u) * chunk, hi = lo + chunk < batch ? lo + chunk : batch;
+    size_t t = lo + (blockIdx.x >> 3);
+    if (t >= hi) return;
+    c32 nxt[kPoints];
+#pragma unroll
+    for (int m = 0; m < kPoints; ++m) nxt[m] = load_stream(in + t * N + lt + T * m);
+    for (; t < hi; t += per_xcd) {
+        c32 r[kPoints];
+#pragma unroll
+        for (int m = 0; m < kPoints; ++m) r[m] = nxt[m];
+        if (t + per_xcd < hi) {
+#pragma unroll
+            for (int m = 0; m < kPoints; ++m) nxt[m] = load_stream(in + (t + per_xcd) * N + lt + T * m);
+        }
+        fft_passes<LOG2N, SIGN>(r, big_lds, lt, 0);
+        __syncthreads();  // the last image has been read before the next transform's first exchange
+#pragma unroll
+        for (int m = 0; m < kPoints; ++m) store_stream(out + t * N + lt + T * m, r[m]);
     }
 }
 
@@ -412,11 +448,30 @@ int launch_large(const c32 *in, c32 *out, int log2n, size_t batch, int direction
 
 }  // namespace
 
+namespace {
+template <int LOG2N>
+int launch_big(const c32 *in, c32 *out, size_t batch, int direction, hipStream_t s) {
+    constexpr int N = 1 << LOG2N;
+    const size_t lds_bytes = static_cast<size_t>(N + N / 16) * sizeof(c32);
+    const size_t chunk = (batch + 7) / 8;
+    const size_t per_xcd = std::min<size_t>(chunk, 32 * (LOG2N == 13 ? 2 : 1));  // resident workgroups per XCD
+    auto kf = fft_big_kernel<LOG2N, +1>;
+    auto ki = fft_big_kernel<LOG2N, -1>;
+    auto kern = direction == DSP_GPU_FORWARD ? kf : ki;
+    DSPGPU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   static_cast<int>(lds_bytes)));
+    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(8 * per_xcd)), dim3(N / kPoints), lds_bytes, s, in, out, batch, chunk);
+    return check_launch("fft_big_kernel");
+}
+}  // namespace
+
 int launch_fft_batch(const float2 *in_f2, float2 *out_f2, int log2n, size_t batch, int direction, hipStream_t s) {
     const c32 *in = reinterpret_cast<const c32 *>(in_f2);
     c32 *out = reinterpret_cast<c32 *>(out_f2);
     if (batch == 0) return DSP_GPU_OK;
     if (log2n <= 12) return dispatch_small<false, false>(log2n, in, out, batch, 0, 0, direction, s);
+    if (log2n == 13) return launch_big<13>(in, out, batch, direction, s);  // one HBM pass: 338 against 187 GSamples/s
+    if (log2n == 14) return launch_big<14>(in, out, batch, direction, s);  //               317 against 190
     return launch_large(in, out, log2n, batch, direction, s);
 }
 

@@ -52,7 +52,7 @@ DSP_DEV void lds_exchange(c32 (&r)[kPoints], c32 *lds, int lt, int base) {
 // The caller must make sure no thread still reads `lds` from an earlier use (barrier).
 template <int LOG2N, int SIGN>
 DSP_DEV void fft_passes(c32 (&r)[kPoints], c32 *lds, int lt, int base) {
-    constexpr int R0 = radix_at(LOG2N, 0), R1 = radix_at(LOG2N, 1), R2 = radix_at(LOG2N, 2);
+    constexpr int R0 = radix_at(LOG2N, 0), R1 = radix_at(LOG2N, 1), R2 = radix_at(LOG2N, 2), R3 = radix_at(LOG2N, 3);
     stockham_pass<R0, 1, LOG2N, SIGN, kPoints>(r, lt);
     if constexpr (R1 > 1) {
         lds_exchange<R0, 1, LOG2N>(r, lds, lt, base);
@@ -61,6 +61,11 @@ DSP_DEV void fft_passes(c32 (&r)[kPoints], c32 *lds, int lt, int base) {
             __syncthreads();  // every thread has finished reading the image of exchange 1
             lds_exchange<R1, R0, LOG2N>(r, lds, lt, base);
             stockham_pass<R2, R0 * R1, LOG2N, SIGN, kPoints>(r, lt);
+            if constexpr (R3 > 1) {  // 2^13 and 2^14 points: one workgroup of N/16 threads (fft_big_kernel)
+                __syncthreads();
+                lds_exchange<R2, R0 * R1, LOG2N>(r, lds, lt, base);
+                stockham_pass<R3, R0 * R1 * R2, LOG2N, SIGN, kPoints>(r, lt);
+            }
         }
     }
 }
