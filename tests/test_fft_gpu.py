@@ -217,3 +217,23 @@ def test_errors(ops, dev):
         ops.fft0(torch.zeros(3, 64, dtype=torch.complex128, device=dev))  # fp32 only
     with pytest.raises(capi.DspGpuError):
         ops.fft0(torch.zeros(1, 64, dtype=torch.complex64))  # CPU torch tensor: pass numpy for host memory
+
+
+@pytest.mark.parametrize("log2n,batch", [(13, 1), (13, 1100), (14, 7), (14, 600)])
+def test_single_pass_8k_16k(ops, dev, orc, log2n, batch):
+    """2^13 / 2^14 points live in one workgroup's LDS (fft_big_kernel); the persistent workgroups walk several
+    transforms each once the batch outgrows the chip (1100 > 8*64, 600 > 8*32)."""
+    import torch
+    n = 1 << log2n
+    g = torch.Generator(device=dev).manual_seed(batch)
+    x = torch.view_as_complex(torch.randn(batch, n, 2, device=dev, generator=g))
+    X = ops.fft0(x)
+    for r in sorted({0, batch // 2, batch - 1}):
+        want = orc.fft0(x[r].cpu().numpy().astype(np.complex128))
+        assert rel_l2(X[r].cpu().numpy(), want) <= budget(log2n)
+    back = ops.fft0(X, inverse=True) / n
+    err = torch.linalg.vector_norm((back - x).view(torch.float32).double()) / torch.linalg.vector_norm(x.view(torch.float32).double())
+    assert float(err) <= 2 * budget(log2n)
+    buf = x.clone()
+    ops.fft0(buf, out=buf)
+    assert torch.equal(buf, X)
