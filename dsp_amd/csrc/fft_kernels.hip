@@ -116,9 +116,10 @@ __global__ __launch_bounds__(kThreads) void fft_lds_kernel(const void *__restric
 // (70 / 139 KB: two / one workgroup per CU), four radix passes, three exchanges.  With so few workgroups per CU
 // nothing else hides the loads, so the workgroups are persistent and fetch the next transform into registers while
 // the current one is transformed.  XCD x owns the contiguous range [x*chunk, (x+1)*chunk) of the batch.
-template <int LOG2N, int SIGN>
-__global__ __launch_bounds__((1 << LOG2N) / kPoints) void fft_big_kernel(const c32 *__restrict__ in, c32 *__restrict__ out,
-                                                                         size_t batch, size_t chunk) {
+template <int LOG2N, int SIGN, bool REAL_IN, bool SHIFTED>
+__global__ __launch_bounds__((1 << LOG2N) / kPoints) void fft_big_kernel(const void *__restrict__ in_, c32 *__restrict__ out,
+                                                                         size_t batch, size_t chunk, size_t n_in,
+                                                                         size_t in_stride) {
     constexpr int N = 1 << LOG2N;
     constexpr int T = N / kPoints;  // threads
     extern __shared__ __attribute__((aligned(16))) c32 big_lds[];
@@ -127,21 +128,35 @@ __global__ __launch_bounds__((1 << LOG2N) / kPoints) void fft_big_kernel(const c
     const size_t lo = static_cast<size_t>(blockIdx.x & 7u) * chunk, hi = lo + chunk < batch ? lo + chunk : batch;
     size_t t = lo + (blockIdx.x >> 3);
     if (t >= hi) return;
-    c32 nxt[kPoints];
+    auto fetch = [&](c32 (&v)[kPoints], size_t row) {
+        if constexpr (REAL_IN) {  // rows of real samples, zero padded (fft.h:65-74)
+            const float *src = static_cast<const float *>(in_) + row * in_stride;
 #pragma unroll
-    for (int m = 0; m < kPoints; ++m) nxt[m] = load_stream(in + t * N + lt + T * m);
+            for (int m = 0; m < kPoints; ++m) {
+                const size_t i = lt + T * m;
+                v[m] = mk(i < n_in ? src[i] : 0.0f, 0.0f);
+            }
+        } else {
+            const c32 *src = static_cast<const c32 *>(in_) + row * N;
+#pragma unroll
+            for (int m = 0; m < kPoints; ++m) v[m] = load_stream(src + lt + T * m);
+        }
+    };
+    c32 nxt[kPoints];
+    fetch(nxt, t);
     for (; t < hi; t += per_xcd) {
         c32 r[kPoints];
 #pragma unroll
         for (int m = 0; m < kPoints; ++m) r[m] = nxt[m];
-        if (t + per_xcd < hi) {
-#pragma unroll
-            for (int m = 0; m < kPoints; ++m) nxt[m] = load_stream(in + (t + per_xcd) * N + lt + T * m);
-        }
+        if (t + per_xcd < hi) fetch(nxt, t + per_xcd);
         fft_passes<LOG2N, SIGN>(r, big_lds, lt, 0);
         __syncthreads();  // the last image has been read before the next transform's first exchange
 #pragma unroll
-        for (int m = 0; m < kPoints; ++m) store_stream(out + t * N + lt + T * m, r[m]);
+        for (int m = 0; m < kPoints; ++m) {
+            int k = lt + T * m;
+            if constexpr (SHIFTED) k = (k + N / 2) & (N - 1);  // dsp::shift fused (fft.h:85-94)
+            store_stream(out + t * N + k, r[m]);
+        }
     }
 }
 
@@ -449,18 +464,19 @@ int launch_large(const c32 *in, c32 *out, int log2n, size_t batch, int direction
 }  // namespace
 
 namespace {
-template <int LOG2N>
-int launch_big(const c32 *in, c32 *out, size_t batch, int direction, hipStream_t s) {
+template <int LOG2N, bool REAL_IN, bool SHIFTED>
+int launch_big(const void *in, c32 *out, size_t batch, size_t n_in, size_t in_stride, int direction, hipStream_t s) {
     constexpr int N = 1 << LOG2N;
     const size_t lds_bytes = static_cast<size_t>(N + N / 16) * sizeof(c32);
     const size_t chunk = (batch + 7) / 8;
     const size_t per_xcd = std::min<size_t>(chunk, 32 * (LOG2N == 13 ? 2 : 1));  // resident workgroups per XCD
-    auto kf = fft_big_kernel<LOG2N, +1>;
-    auto ki = fft_big_kernel<LOG2N, -1>;
+    auto kf = fft_big_kernel<LOG2N, +1, REAL_IN, SHIFTED>;
+    auto ki = fft_big_kernel<LOG2N, -1, REAL_IN, SHIFTED>;
     auto kern = direction == DSP_GPU_FORWARD ? kf : ki;
     DSPGPU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    static_cast<int>(lds_bytes)));
-    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(8 * per_xcd)), dim3(N / kPoints), lds_bytes, s, in, out, batch, chunk);
+    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(8 * per_xcd)), dim3(N / kPoints), lds_bytes, s, in, out, batch, chunk,
+                       n_in, in_stride);
     return check_launch("fft_big_kernel");
 }
 }  // namespace
@@ -470,8 +486,8 @@ int launch_fft_batch(const float2 *in_f2, float2 *out_f2, int log2n, size_t batc
     c32 *out = reinterpret_cast<c32 *>(out_f2);
     if (batch == 0) return DSP_GPU_OK;
     if (log2n <= 12) return dispatch_small<false, false>(log2n, in, out, batch, 0, 0, direction, s);
-    if (log2n == 13) return launch_big<13>(in, out, batch, direction, s);  // one HBM pass: 338 against 187 GSamples/s
-    if (log2n == 14) return launch_big<14>(in, out, batch, direction, s);  //               317 against 190
+    if (log2n == 13) return launch_big<13, false, false>(in, out, batch, 0, 0, direction, s);  // one HBM pass: 338 against 187 GSamples/s
+    if (log2n == 14) return launch_big<14, false, false>(in, out, batch, 0, 0, direction, s);  //               317 against 190
     return launch_large(in, out, log2n, batch, direction, s);
 }
 
@@ -548,6 +564,13 @@ int launch_fft_real_batch(const float *in, size_t n_in, size_t in_stride, float2
     if (log2n <= 12) {
         if (shifted) return dispatch_small<true, true>(log2n, in, out, batch, n_in, in_stride, direction, s);
         return dispatch_small<true, false>(log2n, in, out, batch, n_in, in_stride, direction, s);
+    }
+    if (log2n == 13 || log2n == 14) {  // one HBM pass
+        if (log2n == 13)
+            return shifted ? launch_big<13, true, true>(in, out, batch, n_in, in_stride, direction, s)
+                           : launch_big<13, true, false>(in, out, batch, n_in, in_stride, direction, s);
+        return shifted ? launch_big<14, true, true>(in, out, batch, n_in, in_stride, direction, s)
+                       : launch_big<14, true, false>(in, out, batch, n_in, in_stride, direction, s);
     }
     const size_t n = static_cast<size_t>(1) << log2n;
     const size_t total = batch * n;

@@ -100,7 +100,7 @@ def test_real_wrapper_golden(ops, dev, golden, tag, nf):
 
 
 @pytest.mark.parametrize("n_in,nf,batch", [(100, 128, 4), (300, 300, 3), (4096, 4096, 2), (5000, 4096, 2), (3, 2, 5),
-                                           (20000, 20000, 2), (70000, 1 << 17, 1)])
+                                           (20000, 20000, 2), (70000, 1 << 17, 1), (6000, 8192, 3), (9000, 16384, 2), (16384, 16384, 70)])
 def test_real_wrapper_oracle(ops, dev, orc, n_in, nf, batch):
     import torch
     rng = np.random.default_rng(n_in + nf)
