@@ -28,13 +28,15 @@ struct Buffer {
 };
 
 constexpr size_t kTapCacheEntries = 256;      // a partitioned filter caches one entry per segment
-constexpr int kSegmentTaps = 2048;            // taps per overlap-save pass of a partitioned filter
-constexpr int kMaxPartitionedTaps = 1 << 18;  // 128 passes
+constexpr int kSegmentLog2N = 14;             // partitioned long filters use 16384-point blocks ...
+constexpr int kSegmentTaps = 8192;            // ... of 8192 taps per overlap-save pass (hop 8193)
+constexpr int kMaxPartitionedTaps = 1 << 18;  // 32 passes
 
 struct TapEntry {  // uploaded tap set (+ lazily built overlap-save spectrum)
     std::vector<float> taps;
     float *d_taps = nullptr;
-    float2 *d_spectrum = nullptr;  // 4096-point spectrum of the zero-padded taps
+    float2 *d_spectrum = nullptr;  // spectrum of the zero-padded taps, 2^spec_log2n points
+    int spec_log2n = 0;
 };
 
 struct DeviceState {
@@ -52,7 +54,7 @@ int current_device(int *dev) {
 }
 
 // Find or upload a tap set on the current device.  Sets are tiny (<= 16 KiB) and few.
-int cached_taps(const float *taps, int ntaps, bool want_spectrum, hipStream_t s, TapEntry **out) {
+int cached_taps(const float *taps, int ntaps, int spectrum_log2n, hipStream_t s, TapEntry **out) {  // 0: no spectrum
     int dev = 0;
     if (int rc = current_device(&dev)) return rc;
     std::lock_guard<std::mutex> lock(g_mutex);
@@ -86,10 +88,17 @@ int cached_taps(const float *taps, int ntaps, bool want_spectrum, hipStream_t s,
         st.taps.push_back(std::move(e));
         hit = &st.taps.back();
     }
-    if (want_spectrum && !hit->d_spectrum) {
-        if (hipMalloc(&hit->d_spectrum, sizeof(float2) * 4096) != hipSuccess)
+    if (spectrum_log2n && hit->spec_log2n != spectrum_log2n) {
+        if (hit->d_spectrum) {
+            DSPGPU_HIP(hipDeviceSynchronize());  // an earlier launch may still read the other block length's spectrum
+            (void)hipFree(hit->d_spectrum);
+            hit->d_spectrum = nullptr;
+            hit->spec_log2n = 0;
+        }
+        if (hipMalloc(&hit->d_spectrum, sizeof(float2) << spectrum_log2n) != hipSuccess)
             return fail(DSP_GPU_ENOMEM, "hipMalloc of the tap spectrum failed");
-        if (int rc = launch_fir_spectrum(hit->d_taps, ntaps, hit->d_spectrum, s)) return rc;
+        hit->spec_log2n = spectrum_log2n;
+        if (int rc = launch_fir_spectrum(hit->d_taps, ntaps, hit->d_spectrum, spectrum_log2n, s)) return rc;
         // the spectrum is built on `s`; later users on other streams must see it complete
         DSPGPU_HIP(hipStreamSynchronize(s));
     }
@@ -258,8 +267,8 @@ static int convolve_impl(const char *who, const float *x, float *y, size_t chann
         return fail(DSP_GPU_EINVAL, "%s: mode %d", who, mode);
     if (mode == DSP_GPU_CONV_DIRECT_VALU && history)
         return fail(DSP_GPU_EUNSUPPORTED, "%s: the VALU direct form has no streaming variant", who);
-    // one 4096-point block holds 2049 taps; longer filters run partitioned (2048-tap segments, one overlap-save
-    // pass each, accumulated) in the one-shot form
+    // one 4096-point block holds 2049 taps; longer filters run partitioned (8192-tap segments on 16384-point blocks,
+    // one overlap-save pass each, accumulated) in the one-shot form
     const bool partitioned = ntaps > 2049 && !history &&
                              (mode == DSP_GPU_CONV_OVERLAP_SAVE || (mode == DSP_GPU_CONV_AUTO && (ntaps > 4096 || n >= 4096)));
     const int max_taps = partitioned ? kMaxPartitionedTaps : (mode == DSP_GPU_CONV_OVERLAP_SAVE ? 2049 : 4096);
@@ -285,9 +294,9 @@ static int convolve_impl(const char *who, const float *x, float *y, size_t chann
         for (int seg0 = 0; seg0 < ntaps; seg0 += kSegmentTaps) {
             const int len = std::min(kSegmentTaps, ntaps - seg0);
             TapEntry *seg = nullptr;
-            if (int rc = cached_taps(taps + seg0, len, true, s, &seg)) return rc;
+            if (int rc = cached_taps(taps + seg0, len, kSegmentLog2N, s, &seg)) return rc;
             if (int rc = launch_fir_os_segment(dx, dy, channels, n, seg->d_spectrum, len, static_cast<size_t>(seg0),
-                                               seg0 > 0, s))
+                                               seg0 > 0, kSegmentLog2N, s))
                 return rc;
         }
         // filter.h:126,133: outputs without a full window behind them stay zero
@@ -296,7 +305,7 @@ static int convolve_impl(const char *who, const float *x, float *y, size_t chann
         return mem == DSP_GPU_MEM_HOST ? stage_out(y, bytes, s, hs) : DSP_GPU_OK;
     }
     TapEntry *te = nullptr;
-    if (int rc = cached_taps(taps, ntaps, mode == DSP_GPU_CONV_OVERLAP_SAVE, s, &te)) return rc;
+    if (int rc = cached_taps(taps, ntaps, mode == DSP_GPU_CONV_OVERLAP_SAVE ? 12 : 0, s, &te)) return rc;
     const size_t hist_bytes = channels * static_cast<size_t>(ntaps - 1) * sizeof(float);
     const float *dx = x;
     float *dy = y;

@@ -81,8 +81,8 @@ int launch_fir_history(const float *x, size_t n, const float *old_hist, float *n
 int launch_fir_overlap_save(const float *x, float *y, size_t channels, size_t n, const float2 *d_hspec,
                             int ntaps, const float *hist, int zero_head, hipStream_t s);
 int launch_fir_os_segment(const float *x, float *y, size_t channels, size_t n, const float2 *d_hspec, int seg_len,
-                          size_t seg0, int accumulate, hipStream_t s);
-int launch_fir_spectrum(const float *d_taps, int ntaps, float2 *d_hspec, hipStream_t s);
+                          size_t seg0, int accumulate, int log2n, hipStream_t s);
+int launch_fir_spectrum(const float *d_taps, int ntaps, float2 *d_hspec, int log2n, hipStream_t s);
 int launch_moving_average(const float *x, float *y, size_t channels, size_t n, int npoints, hipStream_t s);
 
 struct IirCoef {  // a Coefficients<Poles> without its history (coefficients.h:7-15), double as in the reference

@@ -264,8 +264,7 @@ __global__ __launch_bounds__(kThreads) void fir_direct_valu_kernel(const float *
 // ---------------------------------------------------------------------------------------------
 // overlap-save FIR
 // ---------------------------------------------------------------------------------------------
-constexpr int kOsN = 4096;
-constexpr int kOsLog2N = 12;
+constexpr int kOsLog2N = 12;  // block length of the plain and streaming forms
 
 // hspec: FORWARD spectrum of the zero padded taps (unscaled).  Block b of a channel produces
 // outputs [order + b*L, order + (b+1)*L) from inputs [b*L, b*L + 4096), L = 4096 - order.
@@ -279,12 +278,15 @@ struct OsExtra {
     int zero_hist;   // streaming form over an all-zero history (no `hist` buffer)
 };
 
-__global__ __launch_bounds__(kThreads) void fir_overlap_save_kernel(const float *__restrict__ x, float *__restrict__ y,
+template <int LOG2N>
+__global__ __launch_bounds__((1 << LOG2N) / kPoints) void fir_overlap_save_kernel(const float *__restrict__ x, float *__restrict__ y,
                                                                     size_t n, const c32 *__restrict__ hspec, int ntaps,
                                                                     unsigned pairs_per_channel, size_t tiles, size_t chunk,
                                                                     const float *__restrict__ hist, int zero_head,
                                                                     OsExtra ex) {
-    __shared__ c32 lds[kLdsElems];
+    constexpr int kOsN = 1 << LOG2N;       // block (transform) length: 4096, or 16384 for partitioned long filters
+    constexpr int kThreads = kOsN / kPoints;  // (shadows the file-wide 256)
+    extern __shared__ __attribute__((aligned(16))) c32 lds[];
     const int tid = threadIdx.x;
     const size_t tile = xcd_tile_of(blockIdx.x, chunk);  // each XCD streams a contiguous range of block pairs
     if (tile >= tiles) return;
@@ -319,7 +321,7 @@ __global__ __launch_bounds__(kThreads) void fir_overlap_save_kernel(const float 
             r[m] = mk(va, vb);
         }
     }
-    fft_passes<kOsLog2N, +1>(r, lds, tid, 0);
+    fft_passes<LOG2N, +1>(r, lds, tid, 0);
     constexpr float scale = 1.0f / kOsN;
 #pragma unroll
     for (int m = 0; m < kPoints; ++m) {
@@ -328,7 +330,7 @@ __global__ __launch_bounds__(kThreads) void fir_overlap_save_kernel(const float 
         r[m] = mk(v.x * scale, v.y * scale);
     }
     __syncthreads();  // the forward passes' last LDS image has been read by everyone
-    fft_passes<kOsLog2N, -1>(r, lds, tid, 0);
+    fft_passes<LOG2N, -1>(r, lds, tid, 0);
 
     if (pair == 0 && hoff == 0)  // filter.h:126,133: the first `order` outputs of the channel stay zero
         for (long long j = tid; j < order && j < nn; j += kThreads) yc[j] = 0.0f;
@@ -560,16 +562,17 @@ int launch_fir_direct(const float *x, float *y, size_t channels, size_t n, const
     return check_launch("fir_direct_kernel");
 }
 
-int launch_fir_spectrum(const float *d_taps, int ntaps, float2 *d_hspec_f2, hipStream_t s) {
-    // FORWARD transform of the taps zero padded to 4096 points (the real-input wrapper does the padding)
-    return launch_fft_real_batch(d_taps, static_cast<size_t>(ntaps), static_cast<size_t>(ntaps), d_hspec_f2, kOsLog2N, 1,
+int launch_fir_spectrum(const float *d_taps, int ntaps, float2 *d_hspec_f2, int log2n, hipStream_t s) {
+    // FORWARD transform of the taps zero padded to the block length (the real-input wrapper does the padding)
+    return launch_fft_real_batch(d_taps, static_cast<size_t>(ntaps), static_cast<size_t>(ntaps), d_hspec_f2, log2n, 1,
                                  DSP_GPU_FORWARD, 0, s);
 }
 
 namespace {
 int launch_os(const float *x, float *y, size_t channels, size_t n, const c32 *d_hspec, int ntaps, const float *hist,
-              int zero_head, const OsExtra &ex, hipStream_t s) {
+              int zero_head, const OsExtra &ex, int log2n, hipStream_t s) {
     const long long order = ntaps - 1;
+    const long long kOsN = 1ll << log2n;
     const long long L = kOsN - order;
     const long long nv = static_cast<long long>(n) + ((hist || ex.zero_hist) ? order : 0);  // length of the (virtual) signal
     const long long valid = nv > order ? nv - order : 0;
@@ -579,8 +582,16 @@ int launch_os(const float *x, float *y, size_t channels, size_t n, const c32 *d_
     const size_t tiles = channels * pairs;
     const size_t chunk = (tiles + 7) / 8;
     if (8 * chunk > 0x7fffffffull) return fail(DSP_GPU_EUNSUPPORTED, "overlap-save FIR: grid too large");
-    hipLaunchKernelGGL(fir_overlap_save_kernel, dim3(static_cast<unsigned>(8 * chunk)), dim3(kThreads), 0, s, x, y, n,
-                       d_hspec, ntaps, pairs, tiles, chunk, hist, zero_head, ex);
+    const size_t lds_bytes = static_cast<size_t>(kOsN + kOsN / 16) * sizeof(c32);
+    if (log2n == 14) {
+        DSPGPU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fir_overlap_save_kernel<14>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes)));
+        hipLaunchKernelGGL(fir_overlap_save_kernel<14>, dim3(static_cast<unsigned>(8 * chunk)), dim3(1024), lds_bytes, s, x, y,
+                           n, d_hspec, ntaps, pairs, tiles, chunk, hist, zero_head, ex);
+    } else {
+        hipLaunchKernelGGL(fir_overlap_save_kernel<12>, dim3(static_cast<unsigned>(8 * chunk)), dim3(kThreads), lds_bytes, s, x,
+                           y, n, d_hspec, ntaps, pairs, tiles, chunk, hist, zero_head, ex);
+    }
     return check_launch("fir_overlap_save_kernel");
 }
 }  // namespace
@@ -588,16 +599,16 @@ int launch_os(const float *x, float *y, size_t channels, size_t n, const c32 *d_
 int launch_fir_overlap_save(const float *x, float *y, size_t channels, size_t n, const float2 *d_hspec_f2, int ntaps,
                             const float *hist, int zero_head, hipStream_t s) {
     return launch_os(x, y, channels, n, reinterpret_cast<const c32 *>(d_hspec_f2), ntaps, hist, zero_head,
-                     OsExtra{n, 0, 0, 0}, s);
+                     OsExtra{n, 0, 0, 0}, kOsLog2N, s);
 }
 
 // One segment of a partitioned long filter (taps [seg0, seg0 + seg_len) of it): y[.][seg0 + j] (+)= sum_i h_seg[i] x[.][j - i]
 // for j < n - seg0, every output kept (the samples before x[0] are zeros).
 int launch_fir_os_segment(const float *x, float *y, size_t channels, size_t n, const float2 *d_hspec_f2, int seg_len,
-                          size_t seg0, int accumulate, hipStream_t s) {
+                          size_t seg0, int accumulate, int log2n, hipStream_t s) {
     if (seg0 >= n) return DSP_GPU_OK;
     return launch_os(x, y, channels, n - seg0, reinterpret_cast<const c32 *>(d_hspec_f2), seg_len, nullptr, 0,
-                     OsExtra{n, seg0, accumulate, 1}, s);
+                     OsExtra{n, seg0, accumulate, 1}, log2n, s);
 }
 
 int launch_moving_average(const float *x, float *y, size_t channels, size_t n, int npoints, hipStream_t s) {

@@ -88,7 +88,7 @@ int dsp_gpu_fft_real_batch(const float *in, size_t n_in, size_t in_stride, void 
  * (filter.h:133 -- causal, first ntaps-1 outputs zero).  `taps` is a HOST pointer to
  * ntaps floats shared by all channels (e.g. the fp32 cast of dsp::sinc, dsp.h:47-79).
  * 1 <= ntaps <= 4096 (direct); overlap-save holds 2049 taps per 4096-point block and runs longer filters
- * partitioned -- 2048-tap segments, one pass each, accumulated -- up to 262,144 taps (AUTO does the same above 2049
+ * partitioned -- 8192-tap segments on 16384-point blocks, one pass each, accumulated -- up to 262,144 taps (AUTO does the same above 2049
  * taps).  Device buffers x and y must not overlap
  * (DSP_GPU_EINVAL); host buffers are staged and may.
  */
