@@ -267,19 +267,20 @@ static int convolve_impl(const char *who, const float *x, float *y, size_t chann
         return fail(DSP_GPU_EINVAL, "%s: mode %d", who, mode);
     if (mode == DSP_GPU_CONV_DIRECT_VALU && history)
         return fail(DSP_GPU_EUNSUPPORTED, "%s: the VALU direct form has no streaming variant", who);
-    // one 4096-point block holds 2049 taps; longer filters run partitioned (8192-tap segments on 16384-point blocks,
-    // one overlap-save pass each, accumulated) in the one-shot form
-    const bool partitioned = ntaps > 2049 && !history &&
-                             (mode == DSP_GPU_CONV_OVERLAP_SAVE || (mode == DSP_GPU_CONV_AUTO && (ntaps > 4096 || n >= 4096)));
-    const int max_taps = partitioned ? kMaxPartitionedTaps : (mode == DSP_GPU_CONV_OVERLAP_SAVE ? 2049 : 4096);
+    // a 4096-point block holds 2049 taps, a 16384-point block 8193; longer filters run partitioned (8192-tap segments
+    // on 16384-point blocks, one overlap-save pass each, accumulated) in the one-shot form
+    const bool os_wanted = mode == DSP_GPU_CONV_OVERLAP_SAVE || (mode == DSP_GPU_CONV_AUTO && (ntaps > 4096 || (ntaps >= 64 && n >= 4096)));
+    const bool partitioned = ntaps > kSegmentTaps + 1 && !history && os_wanted;
+    const int os_log2n = ntaps > 2049 ? kSegmentLog2N : 12;
+    const int max_taps = partitioned ? kMaxPartitionedTaps : (os_wanted ? kSegmentTaps + 1 : 4096);
     if (ntaps < 1 || ntaps > max_taps)
         return fail(DSP_GPU_EINVAL, "%s: ntaps %d outside [1,%d] for this mode", who, ntaps, max_taps);
     if (bad_mem(mem)) return fail(DSP_GPU_EINVAL, "%s: mem %d", who, mem);
     if (channels == 0 || n == 0) return DSP_GPU_OK;
     if (device_overlap(x, y, channels * n * sizeof(float), mem))
         return fail(DSP_GPU_EINVAL, "%s: x and y overlap (the filter is not in-place on device buffers)", who);
-    if (mode == DSP_GPU_CONV_AUTO)  // long filters on long signals amortise the FFT blocks
-        mode = (ntaps >= 64 && ntaps <= 2049 && n >= 4096) ? DSP_GPU_CONV_OVERLAP_SAVE : DSP_GPU_CONV_DIRECT;
+    if (mode == DSP_GPU_CONV_AUTO)  // long filters on long signals amortise the FFT blocks (crossover: DESIGN.md 4.4)
+        mode = os_wanted ? DSP_GPU_CONV_OVERLAP_SAVE : DSP_GPU_CONV_DIRECT;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t bytes = channels * n * sizeof(float);
     if (partitioned) {
@@ -305,7 +306,7 @@ static int convolve_impl(const char *who, const float *x, float *y, size_t chann
         return mem == DSP_GPU_MEM_HOST ? stage_out(y, bytes, s, hs) : DSP_GPU_OK;
     }
     TapEntry *te = nullptr;
-    if (int rc = cached_taps(taps, ntaps, mode == DSP_GPU_CONV_OVERLAP_SAVE ? 12 : 0, s, &te)) return rc;
+    if (int rc = cached_taps(taps, ntaps, mode == DSP_GPU_CONV_OVERLAP_SAVE ? os_log2n : 0, s, &te)) return rc;
     const size_t hist_bytes = channels * static_cast<size_t>(ntaps - 1) * sizeof(float);
     const float *dx = x;
     float *dy = y;
@@ -328,7 +329,7 @@ static int convolve_impl(const char *who, const float *x, float *y, size_t chann
     const unsigned long long order = static_cast<unsigned long long>(ntaps - 1);
     const int zero_head = position >= order ? 0 : static_cast<int>(order - position);
     int rc = mode == DSP_GPU_CONV_OVERLAP_SAVE
-                 ? launch_fir_overlap_save(dx, dy, channels, n, te->d_spectrum, ntaps, old_hist, zero_head, s)
+                 ? launch_fir_overlap_save(dx, dy, channels, n, te->d_spectrum, ntaps, old_hist, zero_head, os_log2n, s)
              : mode == DSP_GPU_CONV_DIRECT_VALU ? launch_fir_direct_valu(dx, dy, channels, n, te->d_taps, ntaps, s)
                                                 : launch_fir_direct(dx, dy, channels, n, te->d_taps, ntaps, old_hist, zero_head, s);
     if (rc) return rc;

@@ -79,7 +79,7 @@ int launch_fir_direct_valu(const float *x, float *y, size_t channels, size_t n, 
 int launch_fir_history(const float *x, size_t n, const float *old_hist, float *new_hist, size_t channels,
                        int ntaps, hipStream_t s);
 int launch_fir_overlap_save(const float *x, float *y, size_t channels, size_t n, const float2 *d_hspec,
-                            int ntaps, const float *hist, int zero_head, hipStream_t s);
+                            int ntaps, const float *hist, int zero_head, int log2n, hipStream_t s);
 int launch_fir_os_segment(const float *x, float *y, size_t channels, size_t n, const float2 *d_hspec, int seg_len,
                           size_t seg0, int accumulate, int log2n, hipStream_t s);
 int launch_fir_spectrum(const float *d_taps, int ntaps, float2 *d_hspec, int log2n, hipStream_t s);

@@ -597,9 +597,9 @@ int launch_os(const float *x, float *y, size_t channels, size_t n, const c32 *d_
 }  // namespace
 
 int launch_fir_overlap_save(const float *x, float *y, size_t channels, size_t n, const float2 *d_hspec_f2, int ntaps,
-                            const float *hist, int zero_head, hipStream_t s) {
+                            const float *hist, int zero_head, int log2n, hipStream_t s) {
     return launch_os(x, y, channels, n, reinterpret_cast<const c32 *>(d_hspec_f2), ntaps, hist, zero_head,
-                     OsExtra{n, 0, 0, 0}, kOsLog2N, s);
+                     OsExtra{n, 0, 0, 0}, log2n, s);
 }
 
 // One segment of a partitioned long filter (taps [seg0, seg0 + seg_len) of it): y[.][seg0 + j] (+)= sum_i h_seg[i] x[.][j - i]

@@ -87,10 +87,11 @@ int dsp_gpu_fft_real_batch(const float *in, size_t n_in, size_t in_stride, void 
  * y[ch][j] = sum_{i<ntaps} x[ch][j-i]*taps[i] for j >= ntaps-1 and 0 before that
  * (filter.h:133 -- causal, first ntaps-1 outputs zero).  `taps` is a HOST pointer to
  * ntaps floats shared by all channels (e.g. the fp32 cast of dsp::sinc, dsp.h:47-79).
- * 1 <= ntaps <= 4096 (direct); overlap-save holds 2049 taps per 4096-point block and runs longer filters
- * partitioned -- 8192-tap segments on 16384-point blocks, one pass each, accumulated -- up to 262,144 taps (AUTO does the same above 2049
- * taps).  Device buffers x and y must not overlap
- * (DSP_GPU_EINVAL); host buffers are staged and may.
+ * 1 <= ntaps <= 4096 (direct).  Overlap-save runs on 4096-point blocks up to 2049 taps and on
+ * 16384-point blocks up to 8193 taps; longer filters run partitioned -- 8192-tap segments on
+ * 16384-point blocks, one pass each, accumulated -- up to 262,144 taps (AUTO takes overlap-save
+ * above 4096 taps whatever n is).  Device buffers x and y must not overlap (DSP_GPU_EINVAL);
+ * host buffers are staged and may.
  */
 int dsp_gpu_convolve(const float *x, float *y, size_t channels, size_t n, const float *taps,
                      int ntaps, int mode, int mem, void *stream);
@@ -105,6 +106,7 @@ int dsp_gpu_convolve(const float *x, float *y, size_t channels, size_t n, const 
  * index position + j is below ntaps-1 are zero exactly as in the one-shot call (filter.h:126,133), all
  * others are   y[ch][j] = sum_i taps[i] * (history ++ x)[ntaps-1 + j - i].
  * Feeding a signal in chunks of any sizes therefore reproduces dsp_gpu_convolve on the whole signal.
+ * ntaps <= 4096 (direct), <= 8193 (overlap-save; the partitioned form has no streaming variant).
  */
 int dsp_gpu_convolve_stream(const float *x, float *y, size_t channels, size_t n, const float *taps,
                             int ntaps, float *history, unsigned long long position, int mode, int mem,

@@ -175,8 +175,8 @@ def test_errors(ops, dev):
     x = torch.zeros(2, 100, device=dev)
     with pytest.raises(capi.DspGpuError):
         ops.convolve(x, np.zeros((1 << 18) + 1), "overlap_save")  # beyond the partitioned limit
-    with pytest.raises(capi.DspGpuError):  # no streaming variant of the partitioned form
-        ops.convolve_stream(x, np.zeros(3000), torch.zeros(2, 2999, device=dev), 0, mode="overlap_save")
+    with pytest.raises(capi.DspGpuError):  # no streaming variant of the partitioned form (more than 8193 taps)
+        ops.convolve_stream(x, np.zeros(9000), torch.zeros(2, 8999, device=dev), 0, mode="overlap_save")
     with pytest.raises(capi.DspGpuError):
         ops.convolve(x, np.zeros(5000), "direct")
     with pytest.raises(capi.DspGpuError):
@@ -186,7 +186,8 @@ def test_errors(ops, dev):
 # ---- streaming FIR (carried input tail) ---------------------------------------------------------------
 @pytest.mark.parametrize("mode,tol", [("direct", DIRECT_TOL), ("overlap_save", OS_TOL)])
 @pytest.mark.parametrize("ntaps,chunks", [(511, [4096, 4096, 4096]), (511, [100, 7000, 3, 511, 510, 5000]),
-                                          (33, [1, 1, 30, 2000]), (2049, [3000, 50, 9000]), (1, [10, 20])])
+                                          (33, [1, 1, 30, 2000]), (2049, [3000, 50, 9000]), (1, [10, 20]),
+                                          (3000, [5000, 100, 9000, 20000])])
 def test_streaming_equals_one_shot(ops, dev, orc, mode, tol, ntaps, chunks):
     """Chunks of any size with the input tail carried == the one-shot call on the whole signal
     (the FIR counterpart of the IIR state; block-wise callers: eval/recursive_filters/main.cpp:174-206)."""
@@ -263,11 +264,13 @@ def _state_after(ops, xd, a, b):
 
 
 # ---- filters longer than one overlap-save block: partitioned ------------------------------------------
-@pytest.mark.parametrize("ntaps,channels,n", [(2050, 2, 20000), (4097, 2, 16000), (6000, 1, 25000), (10001, 2, 12000),
-                                              (5000, 1, 3000), (3000, 2, 2500)])
+@pytest.mark.parametrize("ntaps,channels,n", [(2050, 2, 20000), (4097, 2, 16000), (6000, 1, 25000), (8193, 1, 40000),
+                                              (8194, 1, 40000), (10001, 2, 12000), (20000, 1, 50000), (5000, 1, 3000),
+                                              (3000, 2, 2500)])
 def test_partitioned_long_filters(ops, dev, orc, ntaps, channels, n):
-    """More taps than a 4096-point block holds (2049): 2048-tap segments, one overlap-save pass each, accumulated;
-    the first ntaps-1 outputs stay zero as ever (filter.h:126,133).  Against the reference's direct loop."""
+    """More taps than a 4096-point block holds (2049): 16384-point blocks up to 8193 taps, beyond that partitioned
+    into 8192-tap segments, one overlap-save pass each, accumulated; the first ntaps-1 outputs stay zero as ever
+    (filter.h:126,133).  Against the reference's direct loop."""
     import torch
     from dsp_amd import capi
     rng = np.random.default_rng(ntaps)
