@@ -36,7 +36,16 @@ EXPORTS = (
     "dsp_gpu_swap_axes",
     "dsp_gpu_transpose_blocks",
     "dsp_gpu_fft_rows_exchange",
+    "dsp_gpu_fft_dist_plan_create",
+    "dsp_gpu_fft_dist_plan_create_rccl",
+    "dsp_gpu_fft_dist_local_points",
+    "dsp_gpu_fft_dist",
+    "dsp_gpu_fft_dist_phase",
+    "dsp_gpu_fft_dist_plan_destroy",
 )
+
+# dsp_gpu_exchange_fn: (user, send, recv, block_bytes, world, stream) -> status
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p)
 
 
 class DspGpuError(RuntimeError):
@@ -74,6 +83,16 @@ def lib() -> C.CDLL:
             getattr(L, name).restype = i
         for name in ("dsp_gpu_fft_batch", "dsp_gpu_fft_batch_timed", "dsp_gpu_fft_real_batch", "dsp_gpu_convolve",
                      "dsp_gpu_moving_average", "dsp_gpu_iir", "dsp_gpu_device_count", "dsp_gpu_shutdown"):
+            getattr(L, name).restype = i
+        L.dsp_gpu_fft_dist_plan_create.argtypes = [C.POINTER(vp), i, i, i, EXCHANGE_FN, vp]
+        L.dsp_gpu_fft_dist_plan_create_rccl.argtypes = [C.POINTER(vp), i, i, i, vp]
+        L.dsp_gpu_fft_dist_local_points.argtypes = [vp]
+        L.dsp_gpu_fft_dist_local_points.restype = sz
+        L.dsp_gpu_fft_dist.argtypes = [vp, vp, vp, i, vp]
+        L.dsp_gpu_fft_dist_phase.argtypes = [vp, i, vp, vp, i, vp]
+        L.dsp_gpu_fft_dist_plan_destroy.argtypes = [vp]
+        for name in ("dsp_gpu_fft_dist_plan_create", "dsp_gpu_fft_dist_plan_create_rccl", "dsp_gpu_fft_dist",
+                     "dsp_gpu_fft_dist_phase", "dsp_gpu_fft_dist_plan_destroy"):
             getattr(L, name).restype = i
         L.dsp_gpu_last_error_string.restype = C.c_char_p
         L.dsp_gpu_version.restype = C.c_char_p

@@ -1,0 +1,215 @@
+// dist_plan.hip -- plan handle of the one transform that spans GPUs (BASELINE config 5: a single 2^30-point fft0,
+// reference fft.h:31-55, spread over G ranks).  Host code only: it sequences the local HIP passes of
+// fft_kernels.hip / dist_kernels.hip around three all-to-all exchanges.
+//
+//   N = N1*N2, n = n1*N2 + n2, k = k1 + N1*k2, rank g holds x[g*N/G, (g+1)*N/G) and receives X[g*N/G, (g+1)*N/G):
+//     phase 0  pack          [R][G][C] -> [G][R][C]           (R = N1/G rows, C = N2/G columns)
+//     phase 1  FFT over n1   [N1][C], rows k1 leave grouped by destination rank
+//     phase 2  unpack * W_N^{k1 n2} -> FFT over n2 -> pack    (two fused column passes; three plain ones otherwise)
+//     phase 3  transpose     [G][R][C] -> [C][N1] = X[k1 + N1*k2], natural order
+//   with an exchange (block g of every rank -> rank g) between consecutive phases.
+//
+// The exchange is the caller's (a callback: torch.distributed, MPI, peer copies ...) or RCCL's grouped
+// ncclSend/ncclRecv over the xGMI mesh -- one block per peer, no ring.  RCCL is looked up at run time
+// (dlopen), so the library itself depends on libamdhip64 only.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <mutex>
+
+#include "common.h"
+
+using namespace dspgpu;
+
+struct dsp_gpu_fft_dist_plan {
+    int log2n, rank, world;
+    int log2n1, log2n2;
+    size_t n1, n2, rows, cols, local;  // local = N/G points held by this rank
+    dsp_gpu_exchange_fn exchange;
+    void *user;
+    void *comm;  // ncclComm_t when the built-in exchange is used
+    int device;
+    float2 *work;  // N/G points, allocated on first use on `device`
+};
+
+namespace {
+
+struct Rccl {
+    decltype(&ncclGroupStart) group_start = nullptr;
+    decltype(&ncclGroupEnd) group_end = nullptr;
+    decltype(&ncclSend) send = nullptr;
+    decltype(&ncclRecv) recv = nullptr;
+    decltype(&ncclGetErrorString) error_string = nullptr;
+    bool ok = false;
+};
+
+const Rccl &rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        // the copy already in the process (the caller made its communicator with it) wins: same soname
+        void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) return;
+        r.group_start = reinterpret_cast<decltype(r.group_start)>(dlsym(h, "ncclGroupStart"));
+        r.group_end = reinterpret_cast<decltype(r.group_end)>(dlsym(h, "ncclGroupEnd"));
+        r.send = reinterpret_cast<decltype(r.send)>(dlsym(h, "ncclSend"));
+        r.recv = reinterpret_cast<decltype(r.recv)>(dlsym(h, "ncclRecv"));
+        r.error_string = reinterpret_cast<decltype(r.error_string)>(dlsym(h, "ncclGetErrorString"));
+        r.ok = r.group_start && r.group_end && r.send && r.recv && r.error_string;
+    });
+    return r;
+}
+
+// Block g of `send` goes to rank g, block g of `recv` comes from rank g; every pair of GPUs trades one block.
+int rccl_exchange(void *user, const void *send, void *recv, size_t block_bytes, int world, void *stream) {
+    const Rccl &r = rccl();
+    auto comm = static_cast<ncclComm_t>(user);
+    auto s = static_cast<hipStream_t>(stream);
+    const char *src = static_cast<const char *>(send);
+    char *dst = static_cast<char *>(recv);
+    ncclResult_t e = r.group_start();
+    for (int g = 0; g < world && e == ncclSuccess; ++g) {
+        e = r.send(src + static_cast<size_t>(g) * block_bytes, block_bytes, ncclUint8, g, comm, s);
+        if (e == ncclSuccess) e = r.recv(dst + static_cast<size_t>(g) * block_bytes, block_bytes, ncclUint8, g, comm, s);
+    }
+    const ncclResult_t e2 = r.group_end();
+    if (e == ncclSuccess) e = e2;
+    if (e != ncclSuccess) return fail(DSP_GPU_EHIP, "dsp_gpu_fft_dist: RCCL exchange failed: %s", r.error_string(e));
+    return DSP_GPU_OK;
+}
+
+int make_plan(dsp_gpu_fft_dist_plan **out, int log2n, int rank, int world, dsp_gpu_exchange_fn fn, void *user, void *comm) {
+    if (!out) return fail(DSP_GPU_EINVAL, "dsp_gpu_fft_dist_plan_create: null plan pointer");
+    *out = nullptr;
+    if (world < 1 || (world & (world - 1)) || rank < 0 || rank >= world)
+        return fail(DSP_GPU_EINVAL, "dsp_gpu_fft_dist_plan_create: rank %d of %d (world must be a power of two)", rank, world);
+    const int l1 = (log2n + 1) / 2, l2 = log2n - l1;
+    if (log2n < 8 || l1 > 16 || l2 > 30)
+        return fail(DSP_GPU_EINVAL, "dsp_gpu_fft_dist_plan_create: log2n %d outside [8,32]", log2n);
+    const size_t n1 = static_cast<size_t>(1) << l1, n2 = static_cast<size_t>(1) << l2;
+    if (n1 % world || n2 % world || n2 / world < 2)
+        return fail(DSP_GPU_EINVAL, "dsp_gpu_fft_dist_plan_create: 2^%d points cannot be spread over %d ranks", log2n, world);
+    auto *p = new (std::nothrow) dsp_gpu_fft_dist_plan{};
+    if (!p) return fail(DSP_GPU_ENOMEM, "dsp_gpu_fft_dist_plan_create: out of host memory");
+    p->log2n = log2n, p->rank = rank, p->world = world, p->log2n1 = l1, p->log2n2 = l2;
+    p->n1 = n1, p->n2 = n2, p->rows = n1 / world, p->cols = n2 / world, p->local = p->rows * n2;
+    p->exchange = fn, p->user = user, p->comm = comm, p->device = -1, p->work = nullptr;
+    *out = p;
+    return DSP_GPU_OK;
+}
+
+int work_buffer(dsp_gpu_fft_dist_plan *p, float2 **w) {
+    int dev = 0;
+    DSPGPU_HIP(hipGetDevice(&dev));
+    if (p->work && p->device != dev)
+        return fail(DSP_GPU_EINVAL, "dsp_gpu_fft_dist: plan was first used on device %d, current device is %d", p->device, dev);
+    if (!p->work) {
+        void *v = nullptr;
+        if (hipMalloc(&v, p->local * sizeof(float2)) != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(DSP_GPU_ENOMEM, "dsp_gpu_fft_dist: cannot allocate the %zu-byte work buffer", p->local * sizeof(float2));
+        }
+        p->work = static_cast<float2 *>(v), p->device = dev;
+    }
+    *w = p->work;
+    return DSP_GPU_OK;
+}
+
+int check_direction(const char *who, int direction) {
+    if (direction != DSP_GPU_FORWARD && direction != DSP_GPU_INVERSE) return fail(DSP_GPU_EINVAL, "%s: direction %d", who, direction);
+    return DSP_GPU_OK;
+}
+
+// One local phase, in != out.  `tmp` (N/G points, not `out`; may be `in` if that may be overwritten) is touched only
+// by phase 2 when the fused passes do not cover the shape.
+int run_phase(const dsp_gpu_fft_dist_plan *p, int phase, const float2 *in, float2 *out, float2 *tmp, int direction, hipStream_t s) {
+    const size_t G = p->world, R = p->rows, C = p->cols;
+    switch (phase) {
+    case 0: return launch_swap_axes(in, out, R, G, C, 0, 0, direction, s);
+    case 1: return launch_fft_columns(in, out, p->log2n1, C, direction, s);
+    case 2: {
+        const int rc = launch_fft_rows_exchange(in, out, p->log2n2, R, G, p->log2n, static_cast<unsigned long long>(p->rank) * R,
+                                                direction, s);
+        if (rc != DSP_GPU_EUNSUPPORTED) return rc;
+        if (int e = launch_swap_axes(in, out, G, R, C, p->log2n, static_cast<unsigned long long>(p->rank) * R, direction, s)) return e;
+        if (int e = launch_fft_batch(out, tmp, p->log2n2, R, direction, s)) return e;
+        return launch_swap_axes(tmp, out, R, G, C, 0, 0, direction, s);
+    }
+    case 3: return launch_transpose_blocks(in, out, G, R, C, s);
+    }
+    return fail(DSP_GPU_EINVAL, "dsp_gpu_fft_dist_phase: phase %d outside [0,3]", phase);
+}
+
+}  // namespace
+
+extern "C" {
+
+int dsp_gpu_fft_dist_plan_create(dsp_gpu_fft_dist_plan **plan, int log2n, int rank, int world, dsp_gpu_exchange_fn exchange,
+                                 void *user) {
+    return make_plan(plan, log2n, rank, world, exchange, user, nullptr);
+}
+
+int dsp_gpu_fft_dist_plan_create_rccl(dsp_gpu_fft_dist_plan **plan, int log2n, int rank, int world, void *nccl_comm) {
+    if (!nccl_comm) return fail(DSP_GPU_EINVAL, "dsp_gpu_fft_dist_plan_create_rccl: null communicator");
+    if (!rccl().ok) return fail(DSP_GPU_EUNSUPPORTED, "dsp_gpu_fft_dist_plan_create_rccl: librccl.so not found (%s)", dlerror());
+    return make_plan(plan, log2n, rank, world, rccl_exchange, nccl_comm, nccl_comm);
+}
+
+size_t dsp_gpu_fft_dist_local_points(const dsp_gpu_fft_dist_plan *plan) { return plan ? plan->local : 0; }
+
+int dsp_gpu_fft_dist_phase(dsp_gpu_fft_dist_plan *plan, int phase, const void *in, void *out, int direction, void *stream) {
+    if (!plan || !in || !out || in == out) return fail(DSP_GPU_EINVAL, "dsp_gpu_fft_dist_phase: null plan or null / aliased buffer");
+    if (int rc = check_direction("dsp_gpu_fft_dist_phase", direction)) return rc;
+    if (phase < 0 || phase > 3) return fail(DSP_GPU_EINVAL, "dsp_gpu_fft_dist_phase: phase %d outside [0,3]", phase);
+    float2 *tmp = nullptr;
+    if (phase == 2)
+        if (int rc = work_buffer(plan, &tmp)) return rc;
+    return run_phase(plan, phase, static_cast<const float2 *>(in), static_cast<float2 *>(out), tmp, direction,
+                     static_cast<hipStream_t>(stream));
+}
+
+int dsp_gpu_fft_dist(dsp_gpu_fft_dist_plan *plan, const void *in, void *out, int direction, void *stream) {
+    if (!plan || !in || !out || in == out) return fail(DSP_GPU_EINVAL, "dsp_gpu_fft_dist: null plan or null / aliased buffer");
+    if (int rc = check_direction("dsp_gpu_fft_dist", direction)) return rc;
+    if (plan->world > 1 && !plan->exchange) return fail(DSP_GPU_EINVAL, "dsp_gpu_fft_dist: the plan has no exchange (use the phase calls)");
+    float2 *w = nullptr;
+    if (int rc = work_buffer(plan, &w)) return rc;
+    auto s = static_cast<hipStream_t>(stream);
+    float2 *o = static_cast<float2 *>(out);
+    const size_t block_bytes = plan->local / plan->world * sizeof(float2);
+    const float2 *cur = static_cast<const float2 *>(in);
+    // hops alternate between `out` and the work buffer so that the last one lands in `out`:
+    // seven with exchanges (in->out->w->out->w->out->w->out), four without (in->w->out->w->out).
+    const bool exchanging = plan->exchange != nullptr;  // at world 1 a given exchange still runs (a self copy)
+    float2 *next = exchanging ? o : w;
+    for (int phase = 0; phase < 4; ++phase) {
+        // phase 2's three-pass fallback needs a spare buffer: its input, which its first hop has consumed by then
+        // (never the caller's `in`: that is phase 0's input only)
+        float2 *tmp = phase == 2 ? const_cast<float2 *>(cur) : nullptr;
+        if (int rc = run_phase(plan, phase, cur, next, tmp, direction, s)) return rc;
+        cur = next;
+        next = cur == o ? w : o;
+        if (phase < 3 && exchanging) {
+            if (int rc = plan->exchange(plan->user, cur, next, block_bytes, plan->world, stream))
+                return rc < 0 ? rc : fail(DSP_GPU_EHIP, "dsp_gpu_fft_dist: the exchange callback returned %d", rc);
+            cur = next;
+            next = cur == o ? w : o;
+        }
+    }
+    return DSP_GPU_OK;
+}
+
+int dsp_gpu_fft_dist_plan_destroy(dsp_gpu_fft_dist_plan *plan) {
+    if (!plan) return DSP_GPU_OK;
+    if (plan->work) {
+        int dev = 0;
+        const bool switched = hipGetDevice(&dev) == hipSuccess && dev != plan->device && hipSetDevice(plan->device) == hipSuccess;
+        (void)hipFree(plan->work);
+        if (switched) (void)hipSetDevice(dev);
+    }
+    delete plan;
+    return DSP_GPU_OK;
+}
+
+}  // extern "C"

@@ -264,7 +264,6 @@ __global__ __launch_bounds__(kThreads) void fir_direct_valu_kernel(const float *
 // ---------------------------------------------------------------------------------------------
 // overlap-save FIR
 // ---------------------------------------------------------------------------------------------
-constexpr int kOsLog2N = 12;  // block length of the plain and streaming forms
 
 // hspec: FORWARD spectrum of the zero padded taps (unscaled).  Block b of a channel produces
 // outputs [order + b*L, order + (b+1)*L) from inputs [b*L, b*L + 4096), L = 4096 - order.

@@ -96,8 +96,77 @@ class GpuLocalOps:
         return out
 
 
+class NativePlan:
+    """One rank's dsp_gpu_fft_dist_plan (include/dsp_gpu.h): the phase sequencing lives in the library
+    (dsp_amd/csrc/dist_plan.hip); this object only owns the handle.  `exchange` (optional) is a Python callable
+    (send_ptr, recv_ptr, block_bytes, world, stream) -> int used by `run`; `nccl_comm` selects the built-in RCCL
+    exchange instead."""
+
+    def __init__(self, log2n: int, rank: int, world: int, exchange=None, nccl_comm=None):
+        import ctypes as C
+
+        import torch
+
+        from . import capi
+        self.torch, self.capi = torch, capi
+        self.log2n, self.rank, self.world = log2n, rank, world
+        self._handle = C.c_void_p()
+        if nccl_comm is not None:
+            capi.check(capi.lib().dsp_gpu_fft_dist_plan_create_rccl(C.byref(self._handle), log2n, rank, world, nccl_comm))
+        else:
+            # keep the ctypes thunk alive as long as the plan: the library calls it from dsp_gpu_fft_dist
+            self._thunk = capi.EXCHANGE_FN(
+                (lambda user, send, recv, nbytes, w, stream: int(exchange(send, recv, nbytes, w, stream)))
+                if exchange is not None else 0)
+            capi.check(capi.lib().dsp_gpu_fft_dist_plan_create(C.byref(self._handle), log2n, rank, world, self._thunk, None))
+        self.local_points = capi.lib().dsp_gpu_fft_dist_local_points(self._handle)
+
+    def _stream(self, t):
+        return self.torch.cuda.current_stream(t.device).cuda_stream
+
+    def phase(self, index: int, t, inverse: bool = False):
+        out = self.torch.empty_like(t)
+        self.capi.check(self.capi.lib().dsp_gpu_fft_dist_phase(self._handle, index, t.data_ptr(), out.data_ptr(),
+                                                               int(inverse), self._stream(t)))
+        return out
+
+    def run(self, t, inverse: bool = False, out=None):
+        """The whole transform through dsp_gpu_fft_dist (exchange callback or RCCL communicator of the plan)."""
+        if t.numel() != self.local_points:
+            raise ValueError("x_local must hold N / world points")
+        out = self.torch.empty_like(t) if out is None else out
+        self.capi.check(self.capi.lib().dsp_gpu_fft_dist(self._handle, t.data_ptr(), out.data_ptr(), int(inverse),
+                                                         self._stream(t)))
+        return out
+
+    def close(self):
+        if self._handle:
+            self.capi.lib().dsp_gpu_fft_dist_plan_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_plans: dict = {}
+
+
+def native_phases(log2n: int, rank: int, world: int, inverse: bool):
+    """The same four local phases as `phases`, run by the library's plan handle (the product path on a GPU).
+    Plans are kept per (log2n, rank, world): a plan may own a device work buffer."""
+    plan = _plans.get((log2n, rank, world))
+    if plan is None:
+        plan = _plans[(log2n, rank, world)] = NativePlan(log2n, rank, world)
+    return [lambda t, i=i: plan.phase(i, t, inverse) for i in range(4)]
+
+
 def phases(plan: Plan, rank: int, ops, inverse: bool):
-    """The four local phases of one rank; an all-to-all goes between consecutive phases.
+    """The four local phases of one rank; an all-to-all goes between consecutive phases.  The host-side statement
+    of what dsp_amd/csrc/dist_plan.hip sequences: used with stand-in `ops` to test the index logic on CPU (gloo),
+    and with GpuLocalOps to cross-check the library's plan against its own building blocks.
 
     Every phase maps a flat complex tensor of N/G points to a flat tensor of N/G points laid out as
     G equal blocks (block g goes to / came from rank g)."""
@@ -136,9 +205,8 @@ def fft_dist(x_local, log2n: int, inverse: bool = False, group=None, ops=None):
     plan = make_plan(log2n, world)
     if x_local.numel() != (1 << log2n) // world:
         raise ValueError("x_local must hold N / world points")
-    ops = ops or GpuLocalOps()
-    steps = phases(plan, rank, ops, inverse)
-    t = x_local.reshape(-1)
+    steps = phases(plan, rank, ops, inverse) if ops is not None else native_phases(log2n, rank, world, inverse)
+    t = x_local.reshape(-1).contiguous()
     for i, step in enumerate(steps):
         t = step(t)
         if i + 1 < len(steps) and world > 1:
@@ -156,9 +224,8 @@ def simulate(parts, log2n: int, inverse: bool = False, ops=None):
 
     G = len(parts)
     plan = make_plan(log2n, G)
-    ops = ops or GpuLocalOps()
-    steps = [phases(plan, r, ops, inverse) for r in range(G)]
-    cur = [p.reshape(-1) for p in parts]
+    steps = [phases(plan, r, ops, inverse) if ops is not None else native_phases(log2n, r, G, inverse) for r in range(G)]
+    cur = [p.reshape(-1).contiguous() for p in parts]
     for i in range(4):
         cur = [steps[r][i](cur[r]) for r in range(G)]
         if i < 3:

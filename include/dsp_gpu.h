@@ -156,8 +156,8 @@ int dsp_gpu_iir_multi(const float *x, float *y, size_t channels, size_t n, const
 
 /*
  * Local steps of the multi-GPU six-step FFT: one dsp::fft0 (fft.h:31-55) of N = N1*N2 points spread
- * over G GPUs, n = n1*N2 + n2, k = k1 + N1*k2 (BASELINE config 5).  The three all-to-all exchanges
- * belong to the host layer (dsp_amd/dist_fft.py, RCCL); these run between them.  DEVICE pointers
+ * over G GPUs, n = n1*N2 + n2, k = k1 + N1*k2 (BASELINE config 5) -- the building blocks that
+ * dsp_gpu_fft_dist (below) sequences around its three all-to-all exchanges.  DEVICE pointers
  * only, asynchronous on `stream`, complex fp32 interleaved, in != out.
  *   dsp_gpu_fft_columns       FFT along axis 0 of a row-major [2^log2n][cols] matrix, natural order,
  *                             4 <= log2n <= 16, cols a multiple of 256 (16 when log2n <= 8)
@@ -179,6 +179,44 @@ int dsp_gpu_swap_axes(const void *in, void *out, size_t a, size_t b, size_t c, i
 int dsp_gpu_transpose_blocks(const void *in, void *out, size_t blocks, size_t rows, size_t cols, void *stream);
 int dsp_gpu_fft_rows_exchange(const void *in, void *out, int log2n2, size_t rows, size_t world, int tw_log2n,
                               size_t tw_row0, int direction, void *stream);
+
+/*
+ * One transform spread over several GPUs (BASELINE config 5: a single 2^30-point dsp::fft0, fft.h:31-55; the
+ * reference has no counterpart -- it transforms on one core).  One plan per rank (= per process / host thread
+ * and GPU).  Rank g of `world` (a power of two) holds the contiguous slice x[g*N/G, (g+1)*N/G) in `in` and
+ * receives X[g*N/G, (g+1)*N/G), natural order, in `out`; both are DEVICE buffers of
+ * dsp_gpu_fft_dist_local_points(plan) = N/G complex fp32 points, in != out, `in` is not modified.
+ * 8 <= log2n <= 32; N1 = 2^ceil(log2n/2) and N2 = N/N1 must both be multiples of `world`, N2/world >= 2.
+ * Collective: every rank calls dsp_gpu_fft_dist with the same log2n and direction.  The plan owns one work buffer
+ * of N/G points on the device current at its first use (freed by dsp_gpu_fft_dist_plan_destroy); calls on one
+ * plan must not overlap.
+ *
+ *   dsp_gpu_fft_dist_plan_create       `exchange` performs the all-to-all between phases: block g (block_bytes
+ *                                      bytes) of `send` goes to rank g, block g of `recv` comes from rank g, ordered
+ *                                      on `stream`; device pointers; returns 0 or a negative DSP_GPU_E* code.  It is
+ *                                      called three times per transform.  NULL: only dsp_gpu_fft_dist_phase (or
+ *                                      world == 1) can be used.
+ *   dsp_gpu_fft_dist_plan_create_rccl  the built-in exchange: grouped ncclSend/ncclRecv on the caller's
+ *                                      communicator (an ncclComm_t whose rank/size equal rank/world) -- one block
+ *                                      per peer over the xGMI mesh.  librccl is looked up at run time (dlopen);
+ *                                      DSP_GPU_EUNSUPPORTED when it is not there.
+ *   dsp_gpu_fft_dist                   the whole transform: four local phases, three exchanges (skipped when
+ *                                      world == 1 and the plan has no exchange).
+ *   dsp_gpu_fft_dist_phase             one local phase (0 pack, 1 FFT over n1, 2 twiddle + FFT over n2 + pack,
+ *                                      3 transpose to natural order) for hosts that run the exchange themselves
+ *                                      between phases (dsp_amd/dist_fft.py: torch.distributed all_to_all_single).
+ */
+typedef struct dsp_gpu_fft_dist_plan dsp_gpu_fft_dist_plan;
+typedef int (*dsp_gpu_exchange_fn)(void *user, const void *send, void *recv, size_t block_bytes, int world,
+                                   void *stream);
+int dsp_gpu_fft_dist_plan_create(dsp_gpu_fft_dist_plan **plan, int log2n, int rank, int world,
+                                 dsp_gpu_exchange_fn exchange, void *user);
+int dsp_gpu_fft_dist_plan_create_rccl(dsp_gpu_fft_dist_plan **plan, int log2n, int rank, int world, void *nccl_comm);
+size_t dsp_gpu_fft_dist_local_points(const dsp_gpu_fft_dist_plan *plan);
+int dsp_gpu_fft_dist(dsp_gpu_fft_dist_plan *plan, const void *in, void *out, int direction, void *stream);
+int dsp_gpu_fft_dist_phase(dsp_gpu_fft_dist_plan *plan, int phase, const void *in, void *out, int direction,
+                           void *stream);
+int dsp_gpu_fft_dist_plan_destroy(dsp_gpu_fft_dist_plan *plan);
 
 /* housekeeping */
 int dsp_gpu_device_count(void);

@@ -141,6 +141,41 @@ inline std::vector<std::complex<float>> shift(std::vector<std::complex<float>> d
     return out;
 }
 
+// One fft0 (fft.h:31-55) of 2^log2n points spread over `world` GPUs, one object per rank (process or host thread
+// with its GPU current): rank g passes its contiguous slice of N/world points and receives the same slice of
+// the natural-order result (device pointers, in != out).  Either RCCL trades the blocks (`nccl_comm` = the
+// caller's ncclComm_t) or a caller-supplied exchange does; with neither only `phase` can be used (world > 1).
+class DistributedFft {
+  public:
+    DistributedFft(int log2n, int rank, int world, void *nccl_comm) {
+        check(dsp_gpu_fft_dist_plan_create_rccl(&m_plan, log2n, rank, world, nccl_comm), "DistributedFft");
+    }
+    DistributedFft(int log2n, int rank, int world, dsp_gpu_exchange_fn exchange = nullptr, void *user = nullptr) {
+        check(dsp_gpu_fft_dist_plan_create(&m_plan, log2n, rank, world, exchange, user), "DistributedFft");
+    }
+    DistributedFft(const DistributedFft &) = delete;
+    DistributedFft &operator=(const DistributedFft &) = delete;
+    ~DistributedFft() { dsp_gpu_fft_dist_plan_destroy(m_plan); }
+
+    [[nodiscard]] size_t localPoints() const { return dsp_gpu_fft_dist_local_points(m_plan); }
+
+    template <FFTType type = FFTType::FORWARD>
+    void operator()(const void *in, void *out, void *stream = nullptr) {
+        check(dsp_gpu_fft_dist(m_plan, in, out, type == FFTType::FORWARD ? DSP_GPU_FORWARD : DSP_GPU_INVERSE, stream),
+              "DistributedFft");
+    }
+    // one local phase (0..3) for hosts that run the all-to-all between phases themselves
+    template <FFTType type = FFTType::FORWARD>
+    void phase(int index, const void *in, void *out, void *stream = nullptr) {
+        check(dsp_gpu_fft_dist_phase(m_plan, index, in, out, type == FFTType::FORWARD ? DSP_GPU_FORWARD : DSP_GPU_INVERSE,
+                                     stream),
+              "DistributedFft::phase");
+    }
+
+  private:
+    dsp_gpu_fft_dist_plan *m_plan = nullptr;
+};
+
 // ---- windowed-sinc design (dsp.h) -----------------------------------------------------------------
 enum class Domain : int { Time = 0, Spacial, Frequency };                    // dsp.h:14
 enum class FilterType : int { LowPass, HighPass };                           // dsp.h:16

@@ -54,9 +54,14 @@ def test_veneer_on_gpu(tmp_path, orc, golden, dev):
     fir_in.tofile(os.path.join(d, "fir_in.f32"))
     iir_in = golden["iir_noise_in"]
     iir_in.tofile(os.path.join(d, "iir_in.f32"))
+    dist_in = (rng.standard_normal(1 << 16) + 1j * rng.standard_normal(1 << 16)).astype(np.complex64)
+    dist_in.tofile(os.path.join(d, "dist_in.c64"))
     p = subprocess.run([_exe(), "run", d], capture_output=True, text=True, timeout=110)
     assert p.returncode == 0, p.stderr
     rd = lambda name, dt: np.fromfile(os.path.join(d, name), dtype=dt)
+
+    assert rel_l2(rd("dist_fwd.c64", np.complex64), orc.fft0(dist_in.astype(np.complex128))) <= 1.6e-4
+    assert rel_l2(rd("dist_inv.c64", np.complex64), orc.fft0(dist_in.astype(np.complex128), True)) <= 1.6e-4
 
     fwd = orc.fft0(fft_in.astype(np.complex128))
     assert rel_l2(rd("fft_fwd.c64", np.complex64).reshape(3, 1024), fwd) <= 1e-4

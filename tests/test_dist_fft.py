@@ -113,6 +113,33 @@ def test_shard_range_covers_everything():
         multigpu.shard_range(8, 2, 2)
 
 
+def test_native_plan_arguments():
+    """dsp_gpu_fft_dist_plan_create: argument checks and the slice size (no GPU work)."""
+    import ctypes as C
+    from dsp_amd import capi
+    L = capi.lib()
+    null_fn = capi.EXCHANGE_FN(0)
+    h = C.c_void_p()
+    for log2n, rank, world in ((7, 0, 1), (33, 0, 1), (20, 0, 3), (20, 2, 2), (20, -1, 2), (9, 0, 16), (8, 0, 16)):
+        assert L.dsp_gpu_fft_dist_plan_create(C.byref(h), log2n, rank, world, null_fn, None) == capi.EINVAL, (log2n, rank, world)
+        assert not h.value
+    assert L.dsp_gpu_fft_dist_plan_create(None, 20, 0, 1, null_fn, None) == capi.EINVAL
+    assert L.dsp_gpu_fft_dist_plan_create_rccl(C.byref(h), 20, 0, 1, None) == capi.EINVAL
+    for log2n, world in ((30, 8), (20, 4), (8, 1), (9, 8)):
+        assert L.dsp_gpu_fft_dist_plan_create(C.byref(h), log2n, world - 1, world, null_fn, None) == capi.OK
+        assert L.dsp_gpu_fft_dist_local_points(h) == (1 << log2n) // world
+        assert dist_fft_plan_matches(log2n, world)
+        assert L.dsp_gpu_fft_dist_plan_destroy(h) == capi.OK
+    assert L.dsp_gpu_fft_dist_plan_destroy(None) == capi.OK
+    assert L.dsp_gpu_fft_dist_local_points(None) == 0
+
+
+def dist_fft_plan_matches(log2n, world):
+    from dsp_amd import dist_fft
+    p = dist_fft.make_plan(log2n, world)       # the host-side statement accepts the same shapes
+    return p.rows * p.n2 == (1 << log2n) // world
+
+
 # ---- GPU: the HIP local steps ---------------------------------------------------------------------
 @pytest.mark.gpu
 @pytest.mark.parametrize("log2n,world", [(16, 1), (16, 2), (20, 2), (20, 4), (20, 8), (18, 8), (21, 8)])
@@ -213,3 +240,132 @@ def test_nccl_world_of_one(dev, tmp_path, orc):
         assert rel_l2(out, orc.fft0(x.astype(np.complex128))) <= 1.6e-4
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("log2n", [16, 18, 24])
+def test_native_plan_whole_transform_world_of_one(dev, log2n):
+    """dsp_gpu_fft_dist end to end with one rank (no exchange): against the single-GPU transform."""
+    import torch
+    from dsp_amd import dist_fft, ops
+    g = torch.Generator(device=dev).manual_seed(log2n)
+    x = torch.view_as_complex(torch.randn(1 << log2n, 2, device=dev, generator=g))
+    keep = x.clone()
+    plan = dist_fft.NativePlan(log2n, 0, 1)
+    try:
+        for inverse in (False, True):
+            got = plan.run(x, inverse)
+            want = ops.fft0(x[None], inverse=inverse)[0]
+            err = torch.linalg.vector_norm((got - want).view(torch.float32).double()) / torch.linalg.vector_norm(want.view(torch.float32).double())
+            assert float(err) <= 1e-5 * log2n
+            assert torch.equal(x, keep)          # the input is not modified
+        with pytest.raises(Exception):
+            plan.run(x, out=x)                   # in == out is refused
+    finally:
+        plan.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("log2n,world", [(16, 2), (20, 4), (18, 8), (22, 8)])
+def test_native_plan_with_exchange_callback(orc, dev, log2n, world):
+    """dsp_gpu_fft_dist with a caller-supplied exchange: `world` host threads, one plan each, on one GPU and one
+    stream.  The callback trades blocks with device copies.  A baton keeps one thread at a time inside the
+    library (calls that use the library's scratch must not overlap on a device)."""
+    import ctypes as C
+    import threading
+    import torch
+    from dsp_amd import dist_fft
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+    D2D = 3
+    x = _signal(log2n, seed=7 + log2n)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    baton, barrier = threading.Lock(), threading.Barrier(world)
+    sends = [[None] * world for _ in range(3)]
+    calls = [0] * world
+    errors = []
+
+    def make_exchange(rank):
+        def exchange(send, recv, nbytes, w, s):
+            k = calls[rank]
+            calls[rank] += 1
+            sends[k][rank] = send
+            baton.release()
+            try:
+                barrier.wait(timeout=60)
+            finally:
+                baton.acquire()
+            rc = 0
+            for src in range(w):  # block `rank` of every sender, in sender order
+                if hip.hipMemcpyAsync(recv + src * nbytes, sends[k][src] + rank * nbytes, nbytes, D2D, s) != 0:
+                    rc = -2
+            # nobody may enqueue its next phase (which overwrites its send buffer) before every rank's copies are
+            # enqueued; after that, stream order keeps it safe
+            baton.release()
+            try:
+                barrier.wait(timeout=60)
+            finally:
+                baton.acquire()
+            return rc
+        return exchange
+
+    for inverse in (False, True):
+        parts = [torch.from_numpy(p.copy()).to(dev) for p in np.split(x, world)]
+        outs = [torch.empty_like(p) for p in parts]
+        for c in range(world):
+            calls[c] = 0
+        plans = [dist_fft.NativePlan(log2n, r, world, exchange=make_exchange(r)) for r in range(world)]
+
+        def worker(r):
+            torch.cuda.set_device(dev)
+            with baton:
+                try:
+                    plans[r].capi.check(plans[r].capi.lib().dsp_gpu_fft_dist(plans[r]._handle, parts[r].data_ptr(),
+                                                                            outs[r].data_ptr(), int(inverse), stream))
+                except Exception as e:  # noqa: BLE001
+                    errors.append(e)
+                    barrier.abort()
+
+        threads = [threading.Thread(target=worker, args=(r,)) for r in range(world)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(timeout=120)
+        torch.cuda.synchronize()
+        assert not errors, errors
+        assert calls == [3] * world
+        got = torch.cat(outs).cpu().numpy()
+        assert rel_l2(got, orc.fft0(x.astype(np.complex128), inverse)) <= 1e-5 * log2n
+        for p in plans:
+            p.close()
+
+
+@pytest.mark.gpu
+def test_native_plan_rccl_world_of_one(dev, orc):
+    """The built-in exchange (grouped ncclSend/ncclRecv) on a communicator of one rank made with RCCL's own API."""
+    import ctypes as C
+    import torch
+    from dsp_amd import dist_fft
+
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+
+    try:
+        rccl = C.CDLL("librccl.so.1")
+    except OSError:
+        rccl = C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"))
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+    uid, comm = UniqueId(), C.c_void_p()
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    try:
+        log2n = 16
+        x = _signal(log2n)
+        plan = dist_fft.NativePlan(log2n, 0, 1, nccl_comm=comm)
+        out = plan.run(torch.from_numpy(x).to(dev)).cpu().numpy()
+        assert rel_l2(out, orc.fft0(x.astype(np.complex128))) <= 1.6e-4
+        plan.close()
+    finally:
+        torch.cuda.synchronize()
+        rccl.ncclCommDestroy(comm)
