@@ -40,6 +40,8 @@ def parse():
                     choices=["fft", "fir_direct", "fir_direct_valu", "fir_os", "iir_batch", "iir_scan", "mavg", "fft_dist"])
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: every GPU gets the full per-GPU batch; strong: the one-GPU batch is channel-sharded")
+    ap.add_argument("--dist-exchange", default="torch", choices=["torch", "rccl"],
+                    help="fft_dist only: all_to_all_single between the plan's phases, or dsp_gpu_fft_dist's own RCCL exchange")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the CPU baseline sample")
     ap.add_argument("--cpu-threads", type=int, default=int(os.environ.get("OMP_NUM_THREADS", "0") or 0),
@@ -137,7 +139,7 @@ def make_iir(torch, dev, ops, rank, mode):
     return step, channels * n, meta
 
 
-def make_fft_dist(torch, dev, world, rank):
+def make_fft_dist(torch, dev, world, rank, exchange):
     """C5: ONE transform of world * 2^27 points (2^30 on 8 GPUs), six-step with all-to-all over xGMI."""
     from dsp_amd import dist_fft
     log2n = 27 + (world.bit_length() - 1)
@@ -145,14 +147,24 @@ def make_fft_dist(torch, dev, world, rank):
     g = torch.Generator(device=dev).manual_seed(2030 + rank)
     x = 0.01 * torch.view_as_complex(torch.randn(per_rank, 2, device=dev, generator=g))
 
-    def step():  # the library's plan handle runs the local phases; torch.distributed (RCCL) the exchanges
-        dist_fft.fft_dist(x, log2n, False)
+    if exchange == "rccl":  # all of it inside the library: dsp_gpu_fft_dist with grouped ncclSend/ncclRecv
+        comm = dist_fft.RcclCommunicator(rank, world)
+        plan = dist_fft.NativePlan(log2n, rank, world, nccl_comm=comm.handle)
+        y = torch.empty_like(x)
+
+        def step():
+            plan.run(x, False, out=y)
+    else:
+
+        def step():  # the library's plan handle runs the local phases; torch.distributed (RCCL) the exchanges
+            dist_fft.fft_dist(x, log2n, False)
 
     meta = dict(metric="distributed_fft_throughput", unit="GSamples/s", dtype="f32", bound="hbm",
                 alg_per_unit=48.0, alg_unit="bytes/sample (3 local passes x 16 B; the exchanges ride xGMI)",
                 kernel="fft_column_kernel + fft_lds_kernel + swap_axes_kernel + transpose_blocks_kernel",
                 config={"workload": f"C5: one 2^{log2n}-point complex fp32 FFT, six-step, {world} GPU(s), 2^27 points per GPU",
-                        "log2n": log2n, "exchange": "3 x all_to_all_single (RCCL)"})
+                        "log2n": log2n, "exchange": "3 x grouped ncclSend/ncclRecv inside dsp_gpu_fft_dist" if exchange == "rccl"
+                        else "3 x all_to_all_single (RCCL)"})
     return step, per_rank, meta
 
 
@@ -255,7 +267,7 @@ def main():
     if args.scaling == "strong":
         SHARD = (rank, world)
     if args.workload == "fft_dist":
-        step, units, meta = make_fft_dist(torch, dev, world, rank)
+        step, units, meta = make_fft_dist(torch, dev, world, rank, args.dist_exchange)
     elif args.workload == "fft":
         step, units, meta = make_fft(torch, dev, ops, rank)
     elif args.workload in ("fir_direct", "fir_direct_valu", "fir_os"):

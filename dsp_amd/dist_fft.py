@@ -151,6 +151,46 @@ class NativePlan:
             pass
 
 
+class RcclCommunicator:
+    """An ncclComm_t of our own for the library's built-in exchange (dsp_gpu_fft_dist_plan_create_rccl), made with
+    RCCL's C API through ctypes: rank 0 draws the unique id, torch.distributed (any backend) carries its 128 bytes
+    to the other ranks.  The GPU of this rank must be current."""
+
+    def __init__(self, rank: int, world: int, group=None):
+        import ctypes as C
+        import os
+
+        import torch
+        import torch.distributed as dist
+
+        class UniqueId(C.Structure):
+            _fields_ = [("internal", C.c_char * 128)]
+
+        try:
+            self._rccl = C.CDLL("librccl.so.1")  # the copy torch has loaded already, else the system's
+        except OSError:
+            self._rccl = C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"))
+        self._rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+        self._rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+        uid = UniqueId()
+        if rank == 0 and self._rccl.ncclGetUniqueId(C.byref(uid)) != 0:
+            raise RuntimeError("ncclGetUniqueId failed")
+        if world > 1:
+            box = [None]
+            box[0] = C.string_at(C.addressof(uid), 128) if rank == 0 else None
+            dist.broadcast_object_list(box, src=0, group=group)
+            C.memmove(C.addressof(uid), box[0], 128)
+        self.handle = C.c_void_p()
+        rc = self._rccl.ncclCommInitRank(C.byref(self.handle), world, uid, rank)
+        if rc != 0:
+            raise RuntimeError(f"ncclCommInitRank failed ({rc})")
+
+    def close(self):
+        if self.handle:
+            self._rccl.ncclCommDestroy(self.handle)
+            self.handle = None
+
+
 _plans: dict = {}
 
 

@@ -347,25 +347,14 @@ def test_native_plan_rccl_world_of_one(dev, orc):
     import torch
     from dsp_amd import dist_fft
 
-    class UniqueId(C.Structure):
-        _fields_ = [("internal", C.c_char * 128)]
-
-    try:
-        rccl = C.CDLL("librccl.so.1")
-    except OSError:
-        rccl = C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"))
-    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
-    rccl.ncclCommDestroy.argtypes = [C.c_void_p]
-    uid, comm = UniqueId(), C.c_void_p()
-    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
-    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    comm = dist_fft.RcclCommunicator(0, 1)
     try:
         log2n = 16
         x = _signal(log2n)
-        plan = dist_fft.NativePlan(log2n, 0, 1, nccl_comm=comm)
+        plan = dist_fft.NativePlan(log2n, 0, 1, nccl_comm=comm.handle)
         out = plan.run(torch.from_numpy(x).to(dev)).cpu().numpy()
         assert rel_l2(out, orc.fft0(x.astype(np.complex128))) <= 1.6e-4
         plan.close()
     finally:
         torch.cuda.synchronize()
-        rccl.ncclCommDestroy(comm)
+        comm.close()
