@@ -205,7 +205,12 @@ def _cpu_sample(workload, seconds, seed):
     kind = "reference" if available("ref") else "port"
     lib = load("ref" if kind == "reference" else "fast")
     rng = np.random.default_rng(seed)
-    if workload == "fft":
+    if workload == "fft_f32":  # the like-for-like figure, the same algorithm instantiated in float
+        kind, lib = "port", load("fast")
+        x = (rng.standard_normal((256, 4096)) + 1j * rng.standard_normal((256, 4096))).astype(np.complex64)
+        call, per_call, unit = (lambda: lib.fft0_f32(x)), x.size, "GSamples/s"
+        sample = "{calls} x 256 of 65,536 transforms, the restatement of fft0 instantiated in complex float (the reference has only double)"
+    elif workload == "fft":
         x = (rng.standard_normal((256, 4096)) + 1j * rng.standard_normal((256, 4096)))
         call, per_call, unit = (lambda: lib.fft0(x)), x.size, "GSamples/s"
         sample = "{calls} x 256 of 65,536 transforms, fft0 in complex double as the reference computes (fft.h:31-55)"
@@ -327,6 +332,8 @@ def main():
             line["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_seconds)
             if args.cpu_threads > 1:  # reported beside it, never the target (the roofline fraction is)
                 line["cpu_baseline_all_cores"] = cpu_baseline(args.workload, args.cpu_seconds / 2, args.cpu_threads)
+            if args.workload == "fft":
+                line["cpu_baseline_f32"] = cpu_baseline("fft_f32", args.cpu_seconds / 4)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
