@@ -16,6 +16,7 @@
 //   filter::SincFilter<Inv>::apply       filter.h:123 filter::SincFilter<Inv>::apply(buf [, channels])
 //   filter::MovingAverageFilter::apply   filter.h:81  filter::MovingAverageFilter::apply(buf [, channels])
 //   Coefficients<P>::operator()(buffer)  coefficients.h:88   Coefficients<P>::operator()(buf)
+//   Coefficients<P>::operator()(buffer, CircularBuffer&)  coefficients.h:132,197   operator()(buf, sink)
 //   recursive::lowPassFilter<P>(fc) ...  recursive_filters.h:153-263   same names
 //
 // Buffers: any type with size(), data() and a (size_t) constructor works -- the reference's own
@@ -362,6 +363,18 @@ struct Coefficients {
         }
         x[0] = 0;  // coefficients.h:126
         return output;
+    }
+
+    // coefficients.h:132-170 (generic) and :197-206 (BiQuad): the block-streaming form of the audio callbacks
+    // (eval/recursive_filters/main.cpp:174-206) -- filter one block, continuing from the object's history, and
+    // write sample i to output[i]; `output` is any indexable sink, the reference's CircularBuffer<T, Capacity>
+    // (whose operator[] wraps) included.  Not reproduced from the generic overload: its function-static input
+    // history shared by every filter object (:142), feedback taken from the already wet/dry-mixed ring (:162-165)
+    // and the X[i] index slip (:165); this is the recursion of :106-130 block by block, as the BiQuad overload is.
+    template <typename Buffer, typename Sink>
+    void operator()(const Buffer &input, Sink &output, int mode = DSP_GPU_IIR_AUTO) {
+        const Buffer block = (*this)(input, mode);
+        for (size_t i = 0; i < input.size(); ++i) output[static_cast<int>(i)] = block[static_cast<int>(i)];
     }
 
     // `channels` independent rows filtered with the same coefficients; state[ch][2*Poles] as in the

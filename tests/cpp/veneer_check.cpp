@@ -140,6 +140,22 @@ int run(const std::string &dir) {
         SampleBuffer<float> all(x.begin(), x.end());
         auto ys = shelf(all);
         dump(dir + "/iir_ls.f32", ys.data(), ys.size());
+        // the audio-callback form: 256-frame blocks into a ring that wraps (coefficients.h:132-170,197-206)
+        {
+            struct Ring {  // the part of CircularBuffer<float, 512> the overload touches
+                std::vector<float> slots = std::vector<float>(512);
+                float &operator[](int i) { return slots[static_cast<size_t>(i) % slots.size()]; }
+            } ring;
+            auto streaming = recursive::lowPassFilter<4>(0.1);
+            std::vector<float> collected;
+            for (size_t at = 0; at < x.size(); at += 256) {
+                const size_t len = std::min<size_t>(256, x.size() - at);
+                SampleBuffer<float> block(x.begin() + at, x.begin() + at + len);
+                streaming(block, ring);
+                collected.insert(collected.end(), ring.slots.begin(), ring.slots.begin() + len);
+            }
+            dump(dir + "/iir_ring.f32", collected.data(), collected.size());
+        }
         // batched rows through the same coefficients
         std::vector<float> rows(x.size());
         recursive::lowPassFilter<4>(0.1).apply(x.data(), rows.data(), 4, x.size() / 4);

@@ -85,6 +85,7 @@ def test_veneer_on_gpu(tmp_path, orc, golden, dev):
     ref = golden["cheby_lp4_state_end"]
     assert np.array_equal(st[1:5], ref[1:5]) and st[0] == 0
     assert np.allclose(st[6:10], ref[6:10], rtol=1e-5, atol=1e-7)
+    assert rel_l2(rd("iir_ring.f32", np.float32), golden["cheby_lp4_y64"]) <= 2e-6   # 256-frame blocks, object history
     assert rel_l2(rd("iir_ls.f32", np.float32), golden["bq_ls_y64"]) <= 2e-6
     rows = iir_in.reshape(4, -1).astype(np.float64)
     assert rel_l2(rd("iir_rows.f32", np.float32).reshape(4, -1), orc.iir(rows, golden["cheby_lp4_a"], golden["cheby_lp4_b"])) <= 2e-6
