@@ -70,6 +70,39 @@ def test_fir_random_shapes(ops, dev, orc, seed):
         assert rel_l2(got, orc.moving_average(x.astype(np.float64), npts)) <= 2e-6, (npts, n)
 
 
+@pytest.mark.parametrize("seed", range(4))
+def test_fir_long_filters_and_random_chunking(ops, dev, orc, seed):
+    """Tap counts around the block-length switches (2049 | 2050: 4096- to 16384-point blocks; 8193 | 8194: one pass to
+    partitioned) one-shot, and streamed in random chunks where the streaming form exists (<= 8193 taps)."""
+    import torch
+    from dsp_amd import capi
+    rng = np.random.default_rng(2500 + seed)
+    for _ in range(3):
+        ntaps = int(rng.choice([2048, 2049, 2050, 4096, 4097, 8192, 8193, 8194, int(rng.integers(2050, 8194)),
+                                int(rng.integers(8194, 30000))]))
+        channels, n = int(rng.integers(1, 4)), int(rng.integers(1, 60000))
+        h = (rng.standard_normal(ntaps) / np.sqrt(ntaps)).astype(np.float32)
+        x = rng.standard_normal((channels, n)).astype(np.float32)
+        want = orc.fir(x.astype(np.float64), h.astype(np.float64))
+        xd = torch.from_numpy(x).to(dev)
+        for mode in ("overlap_save", "auto"):
+            got = ops.convolve(xd, h, mode=mode).cpu().numpy()
+            assert rel_l2(got, want) <= 1.4e-4 or not want.any(), (mode, ntaps, channels, n)
+            assert not got[:, : ntaps - 1].any()
+        if ntaps > 8193:
+            with pytest.raises(capi.DspGpuError):
+                ops.convolve_stream(xd, h, torch.zeros(channels, ntaps - 1, device=dev), 0, mode="overlap_save")
+            continue
+        hist = torch.zeros(channels, ntaps - 1, device=dev)
+        pos, outs = 0, []
+        while pos < n:
+            step = int(min(n - pos, rng.choice([1, 7, 100, 4096, 9000, int(rng.integers(1, 30000))])))
+            outs.append(ops.convolve_stream(xd[:, pos:pos + step].contiguous(), h, hist, pos, mode="overlap_save"))
+            pos += step
+        got = torch.cat(outs, dim=1).cpu().numpy()
+        assert rel_l2(got, want) <= 1.4e-4 or not want.any(), ("stream", ntaps, channels, n)
+
+
 @pytest.mark.parametrize("seed", range(6))
 def test_iir_random_shapes(ops, dev, orc, seed):
     import torch
