@@ -280,7 +280,8 @@ struct OsExtra {
 template <int LOG2N>
 __global__ __launch_bounds__((1 << LOG2N) / kPoints) void fir_overlap_save_kernel(const float *__restrict__ x, float *__restrict__ y,
                                                                     size_t n, const c32 *__restrict__ hspec, int ntaps,
-                                                                    unsigned pairs_per_channel, size_t tiles, size_t chunk,
+                                                                    unsigned blocks_per_channel, size_t total_blocks, size_t tiles,
+                                                                    size_t chunk,
                                                                     const float *__restrict__ hist, int zero_head,
                                                                     OsExtra ex) {
     constexpr int kOsN = 1 << LOG2N;       // block (transform) length: 4096, or 16384 for partitioned long filters
@@ -289,25 +290,33 @@ __global__ __launch_bounds__((1 << LOG2N) / kPoints) void fir_overlap_save_kerne
     const int tid = threadIdx.x;
     const size_t tile = xcd_tile_of(blockIdx.x, chunk);  // each XCD streams a contiguous range of block pairs
     if (tile >= tiles) return;
-    const size_t ch = tile / pairs_per_channel;
-    const unsigned pair = static_cast<unsigned>(tile % pairs_per_channel);
+    // the two real blocks riding one complex transform are consecutive entries of the flattened (channel, block)
+    // list: with an odd block count per channel (short channels: often just one) a pair straddles two channels
+    const size_t qa = 2 * tile, qb = qa + 1;
+    const size_t ch_a = qa / blocks_per_channel, ch_b = qb / blocks_per_channel;
+    const unsigned blk_a = static_cast<unsigned>(qa % blocks_per_channel), blk_b = static_cast<unsigned>(qb % blocks_per_channel);
     const long long order = ntaps - 1;
     const long long L = kOsN - order;
     // streaming form: the blocks run over the virtual signal history ++ x (hoff = ntaps-1 samples of
     // history in front), so every output of x is kept; one-shot form: hoff = 0 and y[0, order) = 0
     const long long hoff = (hist || ex.zero_hist) ? order : 0;
     const long long nn = static_cast<long long>(n) + hoff;
-    const float *xc = x + ch * ex.stride - hoff;       // xc[v] valid for v >= hoff
-    float *yc = y + ch * ex.stride + ex.yoff - hoff;
-    const float *hc = hist ? hist + ch * order : nullptr;
-    const long long in_a = static_cast<long long>(2 * pair) * L, in_b = in_a + L;
+    const bool has_b = qb < total_blocks;
+    const float *xa = x + ch_a * ex.stride - hoff;  // xa[v] valid for v >= hoff
+    const float *xb = x + (has_b ? ch_b : ch_a) * ex.stride - hoff;
+    float *ya = y + ch_a * ex.stride + ex.yoff - hoff;
+    float *yb = y + (has_b ? ch_b : ch_a) * ex.stride + ex.yoff - hoff;
+    const float *ha = hist ? hist + ch_a * order : nullptr;
+    const float *hb = hist ? hist + (has_b ? ch_b : ch_a) * order : nullptr;
+    const long long in_a = static_cast<long long>(blk_a) * L;
+    const long long in_b = has_b ? static_cast<long long>(blk_b) * L : nn;  // no second block: nothing loaded, nothing stored
 
     // interior pairs (all but the first of a streamed chunk and the last one or two of a channel) take
     // the unchecked path: the bounds handling costs more VALU work than a radix-16 pass
-    const bool interior = in_a >= hoff && in_b + kOsN <= nn;
+    const bool interior = in_a >= hoff && in_a + kOsN <= nn && in_b >= hoff && in_b + kOsN <= nn;
     c32 r[kPoints];
     if (interior) {
-        const float *pa = xc + in_a + tid, *pb = pa + L;
+        const float *pa = xa + in_a + tid, *pb = xb + in_b + tid;
 #pragma unroll
         for (int m = 0; m < kPoints; ++m)
             r[m] = mk(__builtin_nontemporal_load(pa + kThreads * m), __builtin_nontemporal_load(pb + kThreads * m));
@@ -315,8 +324,8 @@ __global__ __launch_bounds__((1 << LOG2N) / kPoints) void fir_overlap_save_kerne
 #pragma unroll
         for (int m = 0; m < kPoints; ++m) {
             const long long ia = in_a + tid + kThreads * m, ib = in_b + tid + kThreads * m;
-            const float va = ia >= nn ? 0.0f : (ia >= hoff ? __builtin_nontemporal_load(xc + ia) : (hc ? hc[ia] : 0.0f));
-            const float vb = ib >= nn ? 0.0f : (ib >= hoff ? __builtin_nontemporal_load(xc + ib) : (hc ? hc[ib] : 0.0f));
+            const float va = ia >= nn ? 0.0f : (ia >= hoff ? __builtin_nontemporal_load(xa + ia) : (ha ? ha[ia] : 0.0f));
+            const float vb = ib >= nn ? 0.0f : (ib >= hoff ? __builtin_nontemporal_load(xb + ib) : (hb ? hb[ib] : 0.0f));
             r[m] = mk(va, vb);
         }
     }
@@ -331,21 +340,25 @@ __global__ __launch_bounds__((1 << LOG2N) / kPoints) void fir_overlap_save_kerne
     __syncthreads();  // the forward passes' last LDS image has been read by everyone
     fft_passes<LOG2N, -1>(r, lds, tid, 0);
 
-    if (pair == 0 && hoff == 0)  // filter.h:126,133: the first `order` outputs of the channel stay zero
-        for (long long j = tid; j < order && j < nn; j += kThreads) yc[j] = 0.0f;
+    if (hoff == 0) {  // filter.h:126,133: the first `order` outputs of a channel stay zero
+        if (blk_a == 0)
+            for (long long j = tid; j < order && j < nn; j += kThreads) ya[j] = 0.0f;
+        if (has_b && blk_b == 0)
+            for (long long j = tid; j < order && j < nn; j += kThreads) yb[j] = 0.0f;
+    }
     if (ex.accumulate) {  // partitioned form: this segment's contribution on top of the earlier ones
 #pragma unroll
         for (int m = 0; m < kPoints; ++m) {
             const long long k = tid + kThreads * m;
             if (k < order) continue;
             const long long ja = in_a + k, jb = in_b + k;
-            if (ja < nn) yc[ja] += r[m].x;
-            if (jb < nn) yc[jb] += r[m].y;
+            if (ja < nn) ya[ja] += r[m].x;
+            if (jb < nn) yb[jb] += r[m].y;
         }
         return;
     }
     if (interior) {  // every kept output is in range and past the zero head
-        float *pa = yc + in_a + tid, *pb = pa + L;
+        float *pa = ya + in_a + tid, *pb = yb + in_b + tid;
         const int ord = static_cast<int>(order);
 #pragma unroll
         for (int m = 0; m < kPoints; ++m) {
@@ -361,8 +374,8 @@ __global__ __launch_bounds__((1 << LOG2N) / kPoints) void fir_overlap_save_kerne
         if (k < order) continue;  // wrapped (circular) part of the block
         const long long ja = in_a + k, jb = in_b + k;
         // streaming: outputs before the stream's first full window stay zero like the one-shot head
-        if (ja < nn) __builtin_nontemporal_store(ja - hoff < zero_head ? 0.0f : r[m].x, yc + ja);
-        if (jb < nn) __builtin_nontemporal_store(jb - hoff < zero_head ? 0.0f : r[m].y, yc + jb);
+        if (ja < nn) __builtin_nontemporal_store(ja - hoff < zero_head ? 0.0f : r[m].x, ya + ja);
+        if (jb < nn) __builtin_nontemporal_store(jb - hoff < zero_head ? 0.0f : r[m].y, yb + jb);
     }
 }
 
@@ -577,8 +590,9 @@ int launch_os(const float *x, float *y, size_t channels, size_t n, const c32 *d_
     const long long valid = nv > order ? nv - order : 0;
     long long nblocks = (valid + L - 1) / L;
     if (nblocks < 1) nblocks = 1;  // block 0 also zero-fills y[0, order)
-    const unsigned pairs = static_cast<unsigned>((nblocks + 1) / 2);
-    const size_t tiles = channels * pairs;
+    const unsigned bpc = static_cast<unsigned>(nblocks);
+    const size_t total_blocks = channels * static_cast<size_t>(nblocks);
+    const size_t tiles = (total_blocks + 1) / 2;  // two real blocks per complex transform, across channels if need be
     const size_t chunk = (tiles + 7) / 8;
     if (8 * chunk > 0x7fffffffull) return fail(DSP_GPU_EUNSUPPORTED, "overlap-save FIR: grid too large");
     const size_t lds_bytes = static_cast<size_t>(kOsN + kOsN / 16) * sizeof(c32);
@@ -586,10 +600,10 @@ int launch_os(const float *x, float *y, size_t channels, size_t n, const c32 *d_
         DSPGPU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fir_overlap_save_kernel<14>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes)));
         hipLaunchKernelGGL(fir_overlap_save_kernel<14>, dim3(static_cast<unsigned>(8 * chunk)), dim3(1024), lds_bytes, s, x, y,
-                           n, d_hspec, ntaps, pairs, tiles, chunk, hist, zero_head, ex);
+                           n, d_hspec, ntaps, bpc, total_blocks, tiles, chunk, hist, zero_head, ex);
     } else {
         hipLaunchKernelGGL(fir_overlap_save_kernel<12>, dim3(static_cast<unsigned>(8 * chunk)), dim3(kThreads), lds_bytes, s, x,
-                           y, n, d_hspec, ntaps, pairs, tiles, chunk, hist, zero_head, ex);
+                           y, n, d_hspec, ntaps, bpc, total_blocks, tiles, chunk, hist, zero_head, ex);
     }
     return check_launch("fir_overlap_save_kernel");
 }
