@@ -35,8 +35,7 @@ constexpr int kMaxPartitionedTaps = 1 << 18;  // 32 passes
 struct TapEntry {  // uploaded tap set (+ lazily built overlap-save spectrum)
     std::vector<float> taps;
     float *d_taps = nullptr;
-    float2 *d_spectrum = nullptr;  // spectrum of the zero-padded taps, 2^spec_log2n points
-    int spec_log2n = 0;
+    float2 *d_spectrum[15] = {};  // [log2n]: spectrum of the taps zero padded to 2^log2n points (8 ... 12 and 14 in use)
 };
 
 struct DeviceState {
@@ -70,7 +69,8 @@ int cached_taps(const float *taps, int ntaps, int spectrum_log2n, hipStream_t s,
             DSPGPU_HIP(hipDeviceSynchronize());
             for (TapEntry &e : st.taps) {
                 if (e.d_taps) (void)hipFree(e.d_taps);
-                if (e.d_spectrum) (void)hipFree(e.d_spectrum);
+                for (float2 *sp : e.d_spectrum)
+                    if (sp) (void)hipFree(sp);
             }
             st.taps.clear();
         }
@@ -88,22 +88,40 @@ int cached_taps(const float *taps, int ntaps, int spectrum_log2n, hipStream_t s,
         st.taps.push_back(std::move(e));
         hit = &st.taps.back();
     }
-    if (spectrum_log2n && hit->spec_log2n != spectrum_log2n) {
-        if (hit->d_spectrum) {
-            DSPGPU_HIP(hipDeviceSynchronize());  // an earlier launch may still read the other block length's spectrum
-            (void)hipFree(hit->d_spectrum);
-            hit->d_spectrum = nullptr;
-            hit->spec_log2n = 0;
-        }
-        if (hipMalloc(&hit->d_spectrum, sizeof(float2) << spectrum_log2n) != hipSuccess)
+    if (spectrum_log2n < 0 || spectrum_log2n > 14) return fail(DSP_GPU_EINVAL, "tap spectrum of 2^%d points", spectrum_log2n);
+    if (spectrum_log2n && !hit->d_spectrum[spectrum_log2n]) {
+        float2 *sp = nullptr;
+        if (hipMalloc(&sp, sizeof(float2) << spectrum_log2n) != hipSuccess)
             return fail(DSP_GPU_ENOMEM, "hipMalloc of the tap spectrum failed");
-        hit->spec_log2n = spectrum_log2n;
-        if (int rc = launch_fir_spectrum(hit->d_taps, ntaps, hit->d_spectrum, spectrum_log2n, s)) return rc;
+        if (int rc = launch_fir_spectrum(hit->d_taps, ntaps, sp, spectrum_log2n, s)) {
+            (void)hipFree(sp);
+            return rc;
+        }
         // the spectrum is built on `s`; later users on other streams must see it complete
         DSPGPU_HIP(hipStreamSynchronize(s));
+        hit->d_spectrum[spectrum_log2n] = sp;
     }
     *out = hit;
     return DSP_GPU_OK;
+}
+
+// Block length of one overlap-save pass.  4096 points hold 2049 taps, 16384 points 8193.  A channel short enough to
+// fit ONE 4096-point block is cut into the 256- ... 4096-point blocks that cost the fewest butterflies
+// (many short channels -- frames of 1,024 samples, streamed 256-sample audio blocks -- are the case this serves).
+int os_block_log2n(int ntaps, size_t n, bool with_history) {
+    if (ntaps > 2049) return kSegmentLog2N;
+    const long long order = ntaps - 1;
+    const long long valid = with_history ? static_cast<long long>(n) : std::max<long long>(static_cast<long long>(n) - order, 1);
+    if (valid > 4096 - order) return 12;
+    int best = 12;
+    long long best_cost = 4096 * 12;
+    for (int l = 11; l >= 8; --l) {
+        const long long N = 1ll << l, L = N - order;
+        if (L < 1) break;
+        const long long cost = (valid + L - 1) / L * N * l;
+        if (cost < best_cost) best = l, best_cost = cost;
+    }
+    return best;
 }
 
 struct HostStage {  // mem == HOST helper: device mirrors of the caller's buffers
@@ -168,7 +186,8 @@ void release_all_workspaces() {
         }
         for (TapEntry &e : st.taps) {
             if (e.d_taps) (void)hipFree(e.d_taps);
-            if (e.d_spectrum) (void)hipFree(e.d_spectrum);
+            for (float2 *sp : e.d_spectrum)
+                if (sp) (void)hipFree(sp);
         }
         st.taps.clear();
     }
@@ -271,7 +290,7 @@ static int convolve_impl(const char *who, const float *x, float *y, size_t chann
     // on 16384-point blocks, one overlap-save pass each, accumulated) in the one-shot form
     const bool os_wanted = mode == DSP_GPU_CONV_OVERLAP_SAVE || (mode == DSP_GPU_CONV_AUTO && (ntaps > 4096 || (ntaps >= 64 && n >= 256)));  // scripts/fir_crossover.py, fir_short_channels.py
     const bool partitioned = ntaps > kSegmentTaps + 1 && !history && os_wanted;
-    const int os_log2n = ntaps > 2049 ? kSegmentLog2N : 12;
+    const int os_log2n = os_block_log2n(ntaps, n, history != nullptr && position != 0);
     const int max_taps = partitioned ? kMaxPartitionedTaps : (os_wanted ? kSegmentTaps + 1 : 4096);
     if (ntaps < 1 || ntaps > max_taps)
         return fail(DSP_GPU_EINVAL, "%s: ntaps %d outside [1,%d] for this mode", who, ntaps, max_taps);
@@ -296,7 +315,7 @@ static int convolve_impl(const char *who, const float *x, float *y, size_t chann
             const int len = std::min(kSegmentTaps, ntaps - seg0);
             TapEntry *seg = nullptr;
             if (int rc = cached_taps(taps + seg0, len, kSegmentLog2N, s, &seg)) return rc;
-            if (int rc = launch_fir_os_segment(dx, dy, channels, n, seg->d_spectrum, len, static_cast<size_t>(seg0),
+            if (int rc = launch_fir_os_segment(dx, dy, channels, n, seg->d_spectrum[kSegmentLog2N], len, static_cast<size_t>(seg0),
                                                seg0 > 0, kSegmentLog2N, s))
                 return rc;
         }
@@ -329,7 +348,7 @@ static int convolve_impl(const char *who, const float *x, float *y, size_t chann
     const unsigned long long order = static_cast<unsigned long long>(ntaps - 1);
     const int zero_head = position >= order ? 0 : static_cast<int>(order - position);
     int rc = mode == DSP_GPU_CONV_OVERLAP_SAVE
-                 ? launch_fir_overlap_save(dx, dy, channels, n, te->d_spectrum, ntaps, old_hist, zero_head, os_log2n, s)
+                 ? launch_fir_overlap_save(dx, dy, channels, n, te->d_spectrum[os_log2n], ntaps, old_hist, zero_head, os_log2n, s)
              : mode == DSP_GPU_CONV_DIRECT_VALU ? launch_fir_direct_valu(dx, dy, channels, n, te->d_taps, ntaps, s)
                                                 : launch_fir_direct(dx, dy, channels, n, te->d_taps, ntaps, old_hist, zero_head, s);
     if (rc) return rc;

@@ -277,23 +277,28 @@ struct OsExtra {
     int zero_hist;   // streaming form over an all-zero history (no `hist` buffer)
 };
 
+// Workgroup: 256 threads (1,024 for 16384-point blocks); a transform takes T = N/16 of them, so blocks of 256 ... 2,048
+// points (channels short enough to fit one 4096-point block, capi.hip) go sixteen ... two pairs to a workgroup.
 template <int LOG2N>
-__global__ __launch_bounds__((1 << LOG2N) / kPoints) void fir_overlap_save_kernel(const float *__restrict__ x, float *__restrict__ y,
-                                                                    size_t n, const c32 *__restrict__ hspec, int ntaps,
-                                                                    unsigned blocks_per_channel, size_t total_blocks, size_t tiles,
-                                                                    size_t chunk,
-                                                                    const float *__restrict__ hist, int zero_head,
-                                                                    OsExtra ex) {
-    constexpr int kOsN = 1 << LOG2N;       // block (transform) length: 4096, or 16384 for partitioned long filters
-    constexpr int kThreads = kOsN / kPoints;  // (shadows the file-wide 256)
+__global__ __launch_bounds__(((1 << LOG2N) / kPoints) < 256 ? 256 : ((1 << LOG2N) / kPoints)) void fir_overlap_save_kernel(
+    const float *__restrict__ x, float *__restrict__ y, size_t n, const c32 *__restrict__ hspec, int ntaps,
+    unsigned blocks_per_channel, size_t total_blocks, size_t tiles, size_t wg_tiles, size_t chunk,
+    const float *__restrict__ hist, int zero_head, OsExtra ex) {
+    constexpr int kOsN = 1 << LOG2N;    // block (transform) length
+    constexpr int T = kOsN / kPoints;   // threads per transform
+    constexpr int G = T < 256 ? 256 / T : 1;  // transforms (block pairs) per workgroup
     extern __shared__ __attribute__((aligned(16))) c32 lds[];
-    const int tid = threadIdx.x;
-    const size_t tile = xcd_tile_of(blockIdx.x, chunk);  // each XCD streams a contiguous range of block pairs
-    if (tile >= tiles) return;
+    const int lt = static_cast<int>(threadIdx.x) % T, grp = static_cast<int>(threadIdx.x) / T;
+    const int base = grp * kOsN;
+    const size_t wtile = xcd_tile_of(blockIdx.x, chunk);  // each XCD streams a contiguous range of block pairs
+    if (wtile >= wg_tiles) return;
+    const size_t tile = wtile * G + grp;
+    const bool has_a = tile < tiles;  // a workgroup's last transforms may have no pair left: they idle through the barriers
     // the two real blocks riding one complex transform are consecutive entries of the flattened (channel, block)
     // list: with an odd block count per channel (short channels: often just one) a pair straddles two channels
-    const size_t qa = 2 * tile, qb = qa + 1;
-    const size_t ch_a = qa / blocks_per_channel, ch_b = qb / blocks_per_channel;
+    const size_t qa = has_a ? 2 * tile : 0, qb = qa + 1;
+    const bool has_b = has_a && qb < total_blocks;
+    const size_t ch_a = qa / blocks_per_channel, ch_b = has_b ? qb / blocks_per_channel : ch_a;
     const unsigned blk_a = static_cast<unsigned>(qa % blocks_per_channel), blk_b = static_cast<unsigned>(qb % blocks_per_channel);
     const long long order = ntaps - 1;
     const long long L = kOsN - order;
@@ -301,55 +306,55 @@ __global__ __launch_bounds__((1 << LOG2N) / kPoints) void fir_overlap_save_kerne
     // history in front), so every output of x is kept; one-shot form: hoff = 0 and y[0, order) = 0
     const long long hoff = (hist || ex.zero_hist) ? order : 0;
     const long long nn = static_cast<long long>(n) + hoff;
-    const bool has_b = qb < total_blocks;
     const float *xa = x + ch_a * ex.stride - hoff;  // xa[v] valid for v >= hoff
-    const float *xb = x + (has_b ? ch_b : ch_a) * ex.stride - hoff;
+    const float *xb = x + ch_b * ex.stride - hoff;
     float *ya = y + ch_a * ex.stride + ex.yoff - hoff;
-    float *yb = y + (has_b ? ch_b : ch_a) * ex.stride + ex.yoff - hoff;
+    float *yb = y + ch_b * ex.stride + ex.yoff - hoff;
     const float *ha = hist ? hist + ch_a * order : nullptr;
-    const float *hb = hist ? hist + (has_b ? ch_b : ch_a) * order : nullptr;
-    const long long in_a = static_cast<long long>(blk_a) * L;
-    const long long in_b = has_b ? static_cast<long long>(blk_b) * L : nn;  // no second block: nothing loaded, nothing stored
+    const float *hb = hist ? hist + ch_b * order : nullptr;
+    // a missing block starts at nn: nothing is loaded for it and nothing stored
+    const long long in_a = has_a ? static_cast<long long>(blk_a) * L : nn;
+    const long long in_b = has_b ? static_cast<long long>(blk_b) * L : nn;
 
     // interior pairs (all but the first of a streamed chunk and the last one or two of a channel) take
     // the unchecked path: the bounds handling costs more VALU work than a radix-16 pass
     const bool interior = in_a >= hoff && in_a + kOsN <= nn && in_b >= hoff && in_b + kOsN <= nn;
     c32 r[kPoints];
     if (interior) {
-        const float *pa = xa + in_a + tid, *pb = xb + in_b + tid;
+        const float *pa = xa + in_a + lt, *pb = xb + in_b + lt;
 #pragma unroll
         for (int m = 0; m < kPoints; ++m)
-            r[m] = mk(__builtin_nontemporal_load(pa + kThreads * m), __builtin_nontemporal_load(pb + kThreads * m));
+            r[m] = mk(__builtin_nontemporal_load(pa + T * m), __builtin_nontemporal_load(pb + T * m));
     } else {
 #pragma unroll
         for (int m = 0; m < kPoints; ++m) {
-            const long long ia = in_a + tid + kThreads * m, ib = in_b + tid + kThreads * m;
+            const long long ia = in_a + lt + T * m, ib = in_b + lt + T * m;
             const float va = ia >= nn ? 0.0f : (ia >= hoff ? __builtin_nontemporal_load(xa + ia) : (ha ? ha[ia] : 0.0f));
             const float vb = ib >= nn ? 0.0f : (ib >= hoff ? __builtin_nontemporal_load(xb + ib) : (hb ? hb[ib] : 0.0f));
             r[m] = mk(va, vb);
         }
     }
-    fft_passes<LOG2N, +1>(r, lds, tid, 0);
+    fft_passes<LOG2N, +1>(r, lds, lt, base);
     constexpr float scale = 1.0f / kOsN;
 #pragma unroll
     for (int m = 0; m < kPoints; ++m) {
-        const c32 h = hspec[tid + kThreads * m];
+        const c32 h = hspec[lt + T * m];
         const c32 v = cmul(r[m], h);
         r[m] = mk(v.x * scale, v.y * scale);
     }
     __syncthreads();  // the forward passes' last LDS image has been read by everyone
-    fft_passes<LOG2N, -1>(r, lds, tid, 0);
+    fft_passes<LOG2N, -1>(r, lds, lt, base);
 
     if (hoff == 0) {  // filter.h:126,133: the first `order` outputs of a channel stay zero
-        if (blk_a == 0)
-            for (long long j = tid; j < order && j < nn; j += kThreads) ya[j] = 0.0f;
+        if (has_a && blk_a == 0)
+            for (long long j = lt; j < order && j < nn; j += T) ya[j] = 0.0f;
         if (has_b && blk_b == 0)
-            for (long long j = tid; j < order && j < nn; j += kThreads) yb[j] = 0.0f;
+            for (long long j = lt; j < order && j < nn; j += T) yb[j] = 0.0f;
     }
     if (ex.accumulate) {  // partitioned form: this segment's contribution on top of the earlier ones
 #pragma unroll
         for (int m = 0; m < kPoints; ++m) {
-            const long long k = tid + kThreads * m;
+            const long long k = lt + T * m;
             if (k < order) continue;
             const long long ja = in_a + k, jb = in_b + k;
             if (ja < nn) ya[ja] += r[m].x;
@@ -358,19 +363,19 @@ __global__ __launch_bounds__((1 << LOG2N) / kPoints) void fir_overlap_save_kerne
         return;
     }
     if (interior) {  // every kept output is in range and past the zero head
-        float *pa = ya + in_a + tid, *pb = yb + in_b + tid;
+        float *pa = ya + in_a + lt, *pb = yb + in_b + lt;
         const int ord = static_cast<int>(order);
 #pragma unroll
         for (int m = 0; m < kPoints; ++m) {
-            if (tid + kThreads * m < ord) continue;  // wrapped (circular) part of the block
-            __builtin_nontemporal_store(r[m].x, pa + kThreads * m);
-            __builtin_nontemporal_store(r[m].y, pb + kThreads * m);
+            if (lt + T * m < ord) continue;  // wrapped (circular) part of the block
+            __builtin_nontemporal_store(r[m].x, pa + T * m);
+            __builtin_nontemporal_store(r[m].y, pb + T * m);
         }
         return;
     }
 #pragma unroll
     for (int m = 0; m < kPoints; ++m) {
-        const long long k = tid + kThreads * m;
+        const long long k = lt + T * m;
         if (k < order) continue;  // wrapped (circular) part of the block
         const long long ja = in_a + k, jb = in_b + k;
         // streaming: outputs before the stream's first full window stay zero like the one-shot head
@@ -593,18 +598,30 @@ int launch_os(const float *x, float *y, size_t channels, size_t n, const c32 *d_
     const unsigned bpc = static_cast<unsigned>(nblocks);
     const size_t total_blocks = channels * static_cast<size_t>(nblocks);
     const size_t tiles = (total_blocks + 1) / 2;  // two real blocks per complex transform, across channels if need be
-    const size_t chunk = (tiles + 7) / 8;
+    const size_t per_wg = kOsN < 4096 ? static_cast<size_t>(4096 / kOsN) : 1;  // transforms per workgroup
+    const size_t wg_tiles = (tiles + per_wg - 1) / per_wg;
+    const size_t chunk = (wg_tiles + 7) / 8;
     if (8 * chunk > 0x7fffffffull) return fail(DSP_GPU_EUNSUPPORTED, "overlap-save FIR: grid too large");
-    const size_t lds_bytes = static_cast<size_t>(kOsN + kOsN / 16) * sizeof(c32);
-    if (log2n == 14) {
+    const size_t points = static_cast<size_t>(kOsN < 4096 ? 4096 : kOsN);
+    const size_t lds_bytes = (points + points / 16) * sizeof(c32);
+    const dim3 grid(static_cast<unsigned>(8 * chunk));
+#define DSPGPU_OS_LAUNCH(LOG2N, THREADS)                                                                               \
+    hipLaunchKernelGGL(fir_overlap_save_kernel<LOG2N>, grid, dim3(THREADS), lds_bytes, s, x, y, n, d_hspec, ntaps, bpc, \
+                       total_blocks, tiles, wg_tiles, chunk, hist, zero_head, ex)
+    switch (log2n) {
+    case 8: DSPGPU_OS_LAUNCH(8, 256); break;
+    case 9: DSPGPU_OS_LAUNCH(9, 256); break;
+    case 10: DSPGPU_OS_LAUNCH(10, 256); break;
+    case 11: DSPGPU_OS_LAUNCH(11, 256); break;
+    case 12: DSPGPU_OS_LAUNCH(12, 256); break;
+    case 14:
         DSPGPU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fir_overlap_save_kernel<14>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes)));
-        hipLaunchKernelGGL(fir_overlap_save_kernel<14>, dim3(static_cast<unsigned>(8 * chunk)), dim3(1024), lds_bytes, s, x, y,
-                           n, d_hspec, ntaps, bpc, total_blocks, tiles, chunk, hist, zero_head, ex);
-    } else {
-        hipLaunchKernelGGL(fir_overlap_save_kernel<12>, dim3(static_cast<unsigned>(8 * chunk)), dim3(kThreads), lds_bytes, s, x,
-                           y, n, d_hspec, ntaps, bpc, total_blocks, tiles, chunk, hist, zero_head, ex);
+        DSPGPU_OS_LAUNCH(14, 1024);
+        break;
+    default: return fail(DSP_GPU_EINVAL, "overlap-save FIR: no kernel for 2^%d-point blocks", log2n);
     }
+#undef DSPGPU_OS_LAUNCH
     return check_launch("fir_overlap_save_kernel");
 }
 }  // namespace

@@ -88,8 +88,8 @@ int dsp_gpu_fft_real_batch(const float *in, size_t n_in, size_t in_stride, void 
  * y[ch][j] = sum_{i<ntaps} x[ch][j-i]*taps[i] for j >= ntaps-1 and 0 before that
  * (filter.h:133 -- causal, first ntaps-1 outputs zero).  `taps` is a HOST pointer to
  * ntaps floats shared by all channels (e.g. the fp32 cast of dsp::sinc, dsp.h:47-79).
- * 1 <= ntaps <= 4096 (direct).  Overlap-save runs on 4096-point blocks up to 2049 taps and on
- * 16384-point blocks up to 8193 taps; longer filters run partitioned -- 8192-tap segments on
+ * 1 <= ntaps <= 4096 (direct).  Overlap-save runs on 4096-point blocks up to 2049 taps (256- ... 2048-point
+ * blocks for channels short enough to fit one 4096-point block) and on 16384-point blocks up to 8193 taps; longer filters run partitioned -- 8192-tap segments on
  * 16384-point blocks, one pass each, accumulated -- up to 262,144 taps (AUTO takes overlap-save
  * above 4096 taps whatever n is).  Device buffers x and y must not overlap (DSP_GPU_EINVAL);
  * host buffers are staged and may.

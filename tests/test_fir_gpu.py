@@ -293,3 +293,28 @@ def test_partitioned_long_filters(ops, dev, orc, ntaps, channels, n):
         assert np.array_equal(ops.convolve(xd, h, mode="auto").cpu().numpy(), g[1:-1])
         with pytest.raises(capi.DspGpuError):
             ops.convolve(xd, h, mode="direct")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,ntaps,channels", [(256, 31, 19), (256, 255, 5), (256, 256, 5), (200, 100, 3), (512, 127, 11), (300, 63, 7), (1024, 511, 7), (1024, 1023, 3), (1024, 1024, 2), (2048, 511, 5),
+                                              (3000, 511, 9), (3000, 63, 1), (1500, 1025, 4), (514 + 510, 511, 33),
+                                              (515 + 510, 511, 33)])
+def test_overlap_save_short_channels(ops, dev, orc, n, ntaps, channels):
+    """Channels that fit one 4096-point block run on 1024- / 2048-point blocks, several transforms to a workgroup, pairs
+    taken across channels (odd channel counts leave transforms of the last workgroup idle)."""
+    import torch
+    rng = np.random.default_rng(n * 7 + ntaps)
+    h = (rng.standard_normal(ntaps) / np.sqrt(ntaps)).astype(np.float32)
+    x = rng.standard_normal((channels, n)).astype(np.float32)
+    want = orc.fir(x.astype(np.float64), h.astype(np.float64))
+    guard = torch.full((channels + 2, n), 3.0, device=dev)
+    ops.convolve(torch.from_numpy(x).to(dev), h, mode="overlap_save", out=guard[1:-1])
+    g = guard.cpu().numpy()
+    assert (g[0] == 3).all() and (g[-1] == 3).all()
+    assert rel_l2(g[1:-1], want) <= OS_TOL
+    assert not g[1:-1][:, : ntaps - 1].any()
+    # the same signal streamed in 256-sample blocks (an audio callback): one small block per call
+    hist = torch.zeros(channels, ntaps - 1, device=dev)
+    xd = torch.from_numpy(x).to(dev)
+    outs = [ops.convolve_stream(xd[:, p:p + 256].contiguous(), h, hist, p, mode="overlap_save") for p in range(0, n, 256)]
+    assert rel_l2(torch.cat(outs, dim=1).cpu().numpy(), want) <= OS_TOL
