@@ -387,8 +387,7 @@ __global__ __launch_bounds__(((1 << LOG2N) / kPoints) < 256 ? 256 : ((1 << LOG2N
 // ---------------------------------------------------------------------------------------------
 // centred moving average
 // ---------------------------------------------------------------------------------------------
-constexpr int kMaPer = 16;                       // outputs per thread
-constexpr int kMaTile = kThreads * kMaPer;       // 4096 outputs per workgroup
+constexpr int kMaPerMax = 16;  // outputs per thread: 16 (4096 outputs per workgroup), fewer for channels shorter than that
 
 DSP_DEV double shfl_up_f64(double v, int delta) {
     int lo = __double2loint(v), hi = __double2hiint(v);
@@ -411,9 +410,10 @@ DSP_DEV int ma_pad(int i) { return i + ((i >> 4) << 2); }  // 4 pad floats per 1
 // consecutive lanes take consecutive outputs, so the LDS reads are conflict-free and the global
 // stores coalesced.  Nothing is carried along the signal, hence none of the reference's accumulated
 // float drift.  LDS: float xs[ma_pad(span)], double pc[chunks], double wave_tot[4].
-template <bool ALIGNED>
+template <bool ALIGNED, int kMaPer>
 __global__ __launch_bounds__(kThreads) void moving_average_kernel(const float *__restrict__ x, float *__restrict__ y,
                                                                   size_t n, int npoints, int span, int cpt) {
+    constexpr int kMaTile = kThreads * kMaPer;
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
     const int chunks = span >> 4;  // span is a multiple of 16
     float *xs = smem_f;
@@ -646,14 +646,28 @@ int launch_moving_average(const float *x, float *y, size_t channels, size_t n, i
     for (; channels > kMaxGridY; channels -= kMaxGridY, x += kMaxGridY * n, y += kMaxGridY * n)  // grid.y is 16 bits
         if (int rc = launch_moving_average(x, y, kMaxGridY, n, npoints, s)) return rc;
     const int window = 2 * (npoints / 2) + 1;
+    // outputs per thread: the full 16 unless the whole channel fits a smaller tile (many short channels would
+    // otherwise stage and scan mostly padding)
+    int per = kMaPerMax;
+    while (per > 1 && static_cast<size_t>(kThreads) * (per / 2) >= n) per /= 2;
+    const int tile = kThreads * per;
     // staged samples: tile + window, + 3 for the aligned start, + 1 so index `up` of the last output exists
-    const int span = ((kMaTile + window + 4 + 15) / 16) * 16;
+    const int span = ((tile + window + 4 + 15) / 16) * 16;
     const int chunks = span / 16;
     const int cpt = (chunks + kThreads - 1) / kThreads;
     const size_t lds_bytes = static_cast<size_t>(span + (span / 16) * 4) * sizeof(float) + static_cast<size_t>(chunks + 4 * cpt) * sizeof(double);
-    const size_t blocks = (n + kMaTile - 1) / kMaTile;
+    const size_t blocks = (n + tile - 1) / tile;
     const bool aligned = (n % 4 == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0);
-    auto kern = aligned ? moving_average_kernel<true> : moving_average_kernel<false>;
+    void (*kern)(const float *, float *, size_t, int, int, int) = nullptr;
+#define DSPGPU_MA_PICK(PER) kern = aligned ? moving_average_kernel<true, PER> : moving_average_kernel<false, PER>
+    switch (per) {
+    case 1: DSPGPU_MA_PICK(1); break;
+    case 2: DSPGPU_MA_PICK(2); break;
+    case 4: DSPGPU_MA_PICK(4); break;
+    case 8: DSPGPU_MA_PICK(8); break;
+    default: DSPGPU_MA_PICK(16); break;
+    }
+#undef DSPGPU_MA_PICK
     if (lds_bytes > 64 * 1024)
         DSPGPU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        static_cast<int>(lds_bytes)));
