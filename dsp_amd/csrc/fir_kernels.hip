@@ -46,28 +46,30 @@ constexpr int kFirPasses = 2;
 constexpr int kFirSeg = 16;        // Toeplitz blocks (of 16 taps) per accumulation segment
 constexpr int kFirOutPerWg = kFirWaves * kFirAcc * kFirTile * kFirPasses;  // 8192 outputs
 
-// LDS: float xs[hist + kFirOutPerWg] followed by 4 shifted, reversed, zero padded copies of the
-// taps, each taps_len = 16*Q + 16 floats:  copy s holds As[w] = h[16Q - s - w].
-template <bool ALIGNED>
+// LDS: `slots` input segments float xs[hist + S] (slots * S = kFirOutPerWg) followed by 4 shifted, reversed, zero
+// padded copies of the taps, each taps_len = 16*Q + 16 floats:  copy s holds As[w] = h[16Q - s - w].
+// Long channels: one slot, S = 8192 outputs of channel blockIdx.y starting at blockIdx.x * 8192.  Channels of at most
+// 4096 samples: S = n rounded up to 1024 (what one wave covers per pass) and the workgroup takes 8192 / S channels at
+// once, each with its own history in front -- otherwise three of the four waves would idle on a 1024-sample channel.
+template <bool ALIGNED, bool MULTI>  // MULTI: more than one slot (kept apart: the slot arithmetic cost the long-channel path 3 %)
 __global__ __launch_bounds__(kFirThreads) void fir_direct_kernel(const float *__restrict__ x, float *__restrict__ y,
-                                                                  size_t n, const float *__restrict__ taps, int ntaps,
-                                                                  int Q, const float *__restrict__ prev, int zero_head) {
+                                                                  size_t n, size_t channels, const float *__restrict__ taps,
+                                                                  int ntaps, int Q, int slots, int S,
+                                                                  const float *__restrict__ prev, int zero_head) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int hist = 16 * (Q - 1);
-    const int xs_len = hist + kFirOutPerWg;
+    const int slot_len = hist + S;
+    const int xs_len = slots * slot_len;
     const int taps_len = 16 * Q + 16;
     float *xs = smem;
     float *as = smem + xs_len;
 
     const int tid = threadIdx.x;
-    const size_t ch = blockIdx.y;
-    const long long chunk0 = static_cast<long long>(blockIdx.x) * kFirOutPerWg;
-    const float *xc = x + ch * n;
-    float *yc = y + ch * n;
+    const size_t ch0 = MULTI ? static_cast<size_t>(blockIdx.y) * slots : blockIdx.y;  // first channel of this workgroup
+    const long long chunk0 = static_cast<long long>(blockIdx.x) * kFirOutPerWg;  // (blockIdx.x == 0 when slots > 1)
     const long long nn = static_cast<long long>(n);
     // streaming form: prev[ch][ntaps-1] holds the samples before x[0] (oldest first) and every output is kept
     const long long hlen = ntaps - 1;
-    const float *hc = prev ? prev + ch * hlen : nullptr;
 
     // taps: 4 shifted reversed copies
     for (int i = tid; i < 4 * taps_len; i += kFirThreads) {
@@ -75,21 +77,27 @@ __global__ __launch_bounds__(kFirThreads) void fir_direct_kernel(const float *__
         const int idx = 16 * Q - s - w;
         as[i] = (idx >= 0 && idx < ntaps) ? taps[idx] : 0.0f;
     }
-    // input segment [chunk0 - hist, chunk0 + OutPerWg), zeros outside the channel
+    // input segment [chunk0 - hist, chunk0 + S) of every slot's channel, zeros outside the channel
     const long long seg0 = chunk0 - hist;
     for (int u = tid * 4; u < xs_len; u += kFirThreads * 4) {
-        const long long g = seg0 + u;
-        float4 v;
-        if (ALIGNED && g >= 0 && g + 3 < nn) {
-            v = *reinterpret_cast<const float4 *>(xc + g);
-        } else {
-            float e[4];
+        const int k = MULTI ? u / slot_len : 0, off = u - k * slot_len;  // slot_len is a multiple of 4: a float4 stays in its slot
+        const size_t ch = ch0 + k;
+        const long long g = seg0 + off;
+        float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (!MULTI || ch < channels) {
+            const float *xc = x + ch * n;
+            const float *hc = prev ? prev + ch * hlen : nullptr;
+            if (ALIGNED && g >= 0 && g + 3 < nn) {
+                v = *reinterpret_cast<const float4 *>(xc + g);
+            } else {
+                float e[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const long long gi = g + q;
-                e[q] = (gi >= 0 && gi < nn) ? xc[gi] : ((hc && gi < 0 && gi >= -hlen) ? hc[hlen + gi] : 0.0f);
+                for (int q = 0; q < 4; ++q) {
+                    const long long gi = g + q;
+                    e[q] = (gi >= 0 && gi < nn) ? xc[gi] : ((hc && gi < 0 && gi >= -hlen) ? hc[hlen + gi] : 0.0f);
+                }
+                v = make_float4(e[0], e[1], e[2], e[3]);
             }
-            v = make_float4(e[0], e[1], e[2], e[3]);
         }
         *reinterpret_cast<float4 *>(xs + u) = v;
     }
@@ -103,9 +111,17 @@ __global__ __launch_bounds__(kFirThreads) void fir_direct_kernel(const float *__
 
 #pragma unroll 1
     for (int pass = 0; pass < kFirPasses; ++pass) {
-        const int tile0 = (pass * kFirWaves + wave) * kFirAcc;  // first of this wave's tiles in the chunk
-        if (chunk0 + static_cast<long long>(tile0) * kFirTile >= nn) break;  // wave-uniform
-        const float *b_ptr = xs + hist + tile0 * kFirTile + 16 * r + 4 * kq;
+        const int tile0 = (pass * kFirWaves + wave) * kFirAcc;  // first of this wave's tiles in the workgroup's 8192 outputs
+        const int k = MULTI ? tile0 * kFirTile / S : 0;         // its slot (S is a multiple of the 1024 outputs of a wave-pass)
+        const int local = tile0 * kFirTile - k * S;             // first output inside the slot
+        const size_t ch = ch0 + k;
+        if (MULTI) {
+            if (k >= slots || ch >= channels || local >= nn) continue;  // wave-uniform
+        } else if (chunk0 + local >= nn) {
+            break;  // wave-uniform
+        }
+        float *yc = y + ch * n;
+        const float *b_ptr = xs + k * slot_len + hist + local + 16 * r + 4 * kq;
         // The taps are summed in segments of kFirSeg blocks (256 taps) with a fresh accumulator each,
         // so the fp32 rounding of a long filter grows like a blocked sum, not like one long chain.
         f32x4 acc[kFirAcc];
@@ -136,7 +152,7 @@ __global__ __launch_bounds__(kFirThreads) void fir_direct_kernel(const float *__
         // D: column = lane & 15, rows 4*(lane >> 4) + i  ->  y[j0 + 16*col + 4*(lane>>4) + i]
 #pragma unroll
         for (int t = 0; t < kFirAcc; ++t) {
-            const long long j = chunk0 + static_cast<long long>(tile0 + t) * kFirTile + 16 * r + 4 * kq;
+            const long long j = chunk0 + local + static_cast<long long>(t) * kFirTile + 16 * r + 4 * kq;
             if (j >= nn) continue;
             float o[4];
 #pragma unroll
@@ -564,18 +580,28 @@ int launch_fir_direct(const float *x, float *y, size_t channels, size_t n, const
                       const float *hist, int zero_head, hipStream_t s) {
     const int order = ntaps - 1;
     const int Q = (order + 15) / 16 + 1;
-    const size_t lds_bytes = (static_cast<size_t>(16 * (Q - 1) + kFirOutPerWg) + 4u * (16 * Q + 16)) * sizeof(float);
-    const size_t blocks = (n + kFirOutPerWg - 1) / kFirOutPerWg;
-    for (; channels > kMaxGridY; channels -= kMaxGridY, x += kMaxGridY * n, y += kMaxGridY * n) {  // grid.y is 16 bits
-        if (int rc = launch_fir_direct(x, y, kMaxGridY, n, d_taps, ntaps, hist, zero_head, s)) return rc;
-        if (hist) hist += kMaxGridY * static_cast<size_t>(order);
+    // channels of at most 4096 samples: several to a workgroup (slots), each rounded up to the 1024 outputs of a wave-pass
+    const int quantum = kFirAcc * kFirTile;
+    const int S = n * 2 <= static_cast<size_t>(kFirOutPerWg) ? static_cast<int>((n + quantum - 1) / quantum) * quantum : kFirOutPerWg;
+    int slots = kFirOutPerWg / S;
+    // every slot carries its own history: keep the workgroup's LDS near 80 KB (two workgroups per CU) for long filters
+    while (slots > 1 && (static_cast<size_t>(slots) * (16 * (Q - 1) + S) + 4u * (16 * Q + 16)) * sizeof(float) > 80u * 1024) slots /= 2;
+    const size_t per_launch = kMaxGridY * static_cast<size_t>(slots);  // grid.y is 16 bits
+    for (; channels > per_launch; channels -= per_launch, x += per_launch * n, y += per_launch * n) {
+        if (int rc = launch_fir_direct(x, y, per_launch, n, d_taps, ntaps, hist, zero_head, s)) return rc;
+        if (hist) hist += per_launch * static_cast<size_t>(order);
     }
+    const size_t lds_bytes = (static_cast<size_t>(slots) * (16 * (Q - 1) + S) + 4u * (16 * Q + 16)) * sizeof(float);
+    const size_t blocks = slots > 1 ? 1 : (n + kFirOutPerWg - 1) / kFirOutPerWg;
+    const size_t groups = (channels + slots - 1) / slots;
     const bool aligned = (n % 4 == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0) && (reinterpret_cast<uintptr_t>(y) % 16 == 0);
-    auto kern = aligned ? fir_direct_kernel<true> : fir_direct_kernel<false>;
+    auto kern = slots > 1 ? (aligned ? fir_direct_kernel<true, true> : fir_direct_kernel<false, true>)
+                          : (aligned ? fir_direct_kernel<true, false> : fir_direct_kernel<false, false>);
     if (lds_bytes > 64 * 1024)
         DSPGPU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        static_cast<int>(lds_bytes)));
-    hipLaunchKernelGGL(kern, dim3(blocks, channels), dim3(kFirThreads), lds_bytes, s, x, y, n, d_taps, ntaps, Q, hist, zero_head);
+    hipLaunchKernelGGL(kern, dim3(blocks, groups), dim3(kFirThreads), lds_bytes, s, x, y, n, channels, d_taps, ntaps, Q, slots, S,
+                       hist, zero_head);
     return check_launch("fir_direct_kernel");
 }
 

@@ -318,3 +318,27 @@ def test_overlap_save_short_channels(ops, dev, orc, n, ntaps, channels):
     xd = torch.from_numpy(x).to(dev)
     outs = [ops.convolve_stream(xd[:, p:p + 256].contiguous(), h, hist, p, mode="overlap_save") for p in range(0, n, 256)]
     assert rel_l2(torch.cat(outs, dim=1).cpu().numpy(), want) <= OS_TOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,ntaps,channels", [(1024, 511, 7), (1000, 63, 9), (100, 31, 20), (2048, 511, 3), (2049, 200, 5),
+                                              (4096, 1023, 3), (4097, 511, 3), (1024, 4096, 5), (3000, 2500, 2), (1, 1, 70000)])
+def test_direct_short_channels(ops, dev, orc, n, ntaps, channels):
+    """Channels of at most 4096 samples go several to a workgroup in the direct (MFMA) kernel, each with its own history
+    in front; one-shot and streamed in 256-sample blocks."""
+    import torch
+    rng = np.random.default_rng(n * 13 + ntaps)
+    h = (rng.standard_normal(ntaps) / np.sqrt(ntaps)).astype(np.float32)
+    x = rng.standard_normal((channels, n)).astype(np.float32)
+    want = orc.fir(x.astype(np.float64), h.astype(np.float64))
+    guard = torch.full((channels + 2, n), 3.0, device=dev)
+    xd = torch.from_numpy(x).to(dev)
+    ops.convolve(xd, h, mode="direct", out=guard[1:-1])
+    g = guard.cpu().numpy()
+    assert (g[0] == 3).all() and (g[-1] == 3).all()
+    assert rel_l2(g[1:-1], want) <= DIRECT_TOL or not want.any()
+    assert not g[1:-1][:, : ntaps - 1].any()
+    if channels <= 100:
+        hist = torch.zeros(channels, ntaps - 1, device=dev)
+        outs = [ops.convolve_stream(xd[:, p:p + 256].contiguous(), h, hist, p, mode="direct") for p in range(0, n, 256)]
+        assert rel_l2(torch.cat(outs, dim=1).cpu().numpy(), want) <= DIRECT_TOL or not want.any()
