@@ -1,12 +1,15 @@
 """Seeded random shapes through every entry point against the oracle: ragged channel counts, lengths that straddle
 tile borders, tap / window / pole counts across the kernels' internal switches.  Sizes stay small enough for the
 CPU oracle to answer in seconds."""
+import os
+
 import numpy as np
 import pytest
 
 from conftest import rel_l2
 
 pytestmark = pytest.mark.gpu
+SEEDS = int(os.environ.get("DSP_FUZZ_SEEDS", "6"))  # a longer soak: DSP_FUZZ_SEEDS=60 python -m pytest tests/test_fuzz_gpu.py
 
 
 @pytest.fixture(scope="module")
@@ -29,7 +32,7 @@ def _stable_section(rng, poles):
     return a, b
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(SEEDS))
 def test_fft_random_shapes(ops, dev, orc, seed):
     import torch
     rng = np.random.default_rng(1000 + seed)
@@ -51,7 +54,7 @@ def test_fft_random_shapes(ops, dev, orc, seed):
             assert got.shape[1] == want.size and rel_l2(got[r], want) <= 1e-5 * max(log2n, 1) + 1e-7, (n_in, nf)
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(SEEDS))
 def test_fir_random_shapes(ops, dev, orc, seed):
     import torch
     rng = np.random.default_rng(2000 + seed)
@@ -70,7 +73,7 @@ def test_fir_random_shapes(ops, dev, orc, seed):
         assert rel_l2(got, orc.moving_average(x.astype(np.float64), npts)) <= 2e-6, (npts, n)
 
 
-@pytest.mark.parametrize("seed", range(4))
+@pytest.mark.parametrize("seed", range(max(SEEDS * 2 // 3, 1)))
 def test_fir_long_filters_and_random_chunking(ops, dev, orc, seed):
     """Tap counts around the block-length switches (2049 | 2050: 4096- to 16384-point blocks; 8193 | 8194: one pass to
     partitioned) one-shot, and streamed in random chunks where the streaming form exists (<= 8193 taps)."""
@@ -103,7 +106,7 @@ def test_fir_long_filters_and_random_chunking(ops, dev, orc, seed):
         assert rel_l2(got, want) <= 1.4e-4 or not want.any(), ("stream", ntaps, channels, n)
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(SEEDS))
 def test_iir_random_shapes(ops, dev, orc, seed):
     import torch
     rng = np.random.default_rng(3000 + seed)
