@@ -57,10 +57,18 @@ __global__ __launch_bounds__(kThreads) void fft_lds_kernel(const void *__restric
     c32 r[kPoints];
     if constexpr (kStaged && !REAL_IN) {
         const c32 *src = static_cast<const c32 *>(in_) + tile * kTile;
+        if (tile_points == static_cast<size_t>(kTile)) {  // full tile: sixteen unconditional loads in flight at once
+            c32 v[kPoints];
 #pragma unroll
-        for (int m = 0; m < kPoints; ++m) {
-            const int e = tid + kThreads * m;
-            lds[padded(e)] = static_cast<size_t>(e) < tile_points ? load_stream(src + e) : mk(0.0f, 0.0f);
+            for (int m = 0; m < kPoints; ++m) v[m] = load_stream(src + tid + kThreads * m);
+#pragma unroll
+            for (int m = 0; m < kPoints; ++m) lds[padded(tid + kThreads * m)] = v[m];
+        } else {
+#pragma unroll
+            for (int m = 0; m < kPoints; ++m) {
+                const int e = tid + kThreads * m;
+                lds[padded(e)] = static_cast<size_t>(e) < tile_points ? load_stream(src + e) : mk(0.0f, 0.0f);
+            }
         }
         __syncthreads();
 #pragma unroll
@@ -96,10 +104,15 @@ __global__ __launch_bounds__(kThreads) void fft_lds_kernel(const void *__restric
         }
         __syncthreads();
         c32 *dst = out + tile * kTile;
+        if (tile_points == static_cast<size_t>(kTile)) {
 #pragma unroll
-        for (int m = 0; m < kPoints; ++m) {
-            const int e = tid + kThreads * m;
-            if (static_cast<size_t>(e) < tile_points) store_stream(dst + e, lds[padded(e)]);
+            for (int m = 0; m < kPoints; ++m) store_stream(dst + tid + kThreads * m, lds[padded(tid + kThreads * m)]);
+        } else {
+#pragma unroll
+            for (int m = 0; m < kPoints; ++m) {
+                const int e = tid + kThreads * m;
+                if (static_cast<size_t>(e) < tile_points) store_stream(dst + e, lds[padded(e)]);
+            }
         }
     } else if (live) {
         c32 *dst = out + xf * N;

@@ -452,8 +452,20 @@ __global__ __launch_bounds__(kThreads) void moving_average_kernel(const float *_
     float *yc = y + ch * n;
     const float corr = ((npoints & 1) == 0 && npoints < nn) ? xc[npoints] : 0.0f;
 
-#pragma unroll 4
-    for (int u = tid * 4; u < span; u += kThreads * 4) {
+    int u0 = tid * 4;
+    if (ALIGNED && seg0 >= 0 && seg0 + span <= nn) {
+        // interior tile: unconditional loads, four in flight per thread (a bounds branch around every load makes the
+        // compiler wait for each one before issuing the next)
+        constexpr int kStep = kThreads * 4;
+        for (; u0 + 3 * kStep < span; u0 += 4 * kStep) {
+            float4 v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = load_stream_f4(xc + seg0 + u0 + i * kStep);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) *reinterpret_cast<float4 *>(xs + ma_pad(u0 + i * kStep)) = v[i];
+        }
+    }
+    for (int u = u0; u < span; u += kThreads * 4) {
         const long long g = seg0 + u;
         float4 v;
         if (ALIGNED && g >= 0 && g + 3 < nn) {

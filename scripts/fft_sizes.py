@@ -8,7 +8,8 @@ from dsp_amd import ops
 total = 1 << 28
 x = torch.randn(total, 2, device="cuda").view(torch.complex64) if False else torch.view_as_complex(torch.randn(total, 2, device="cuda"))
 out = torch.empty_like(x)
-for log2n in (4, 6, 8, 10, 11, 12, 13, 14, 16, 18, 20, 22, 24, 26, 28, 30):
+import os
+for log2n in eval(os.environ.get("FFT_SIZES", "(4, 6, 8, 10, 11, 12, 13, 14, 16, 18, 20, 22, 24, 26, 28, 30)")):
     n = 1 << log2n
     if n > total:  # one transform larger than the sweep's batch: grow the buffers
         total = n
