@@ -79,7 +79,20 @@ __global__ __launch_bounds__(kFirThreads) void fir_direct_kernel(const float *__
     }
     // input segment [chunk0 - hist, chunk0 + S) of every slot's channel, zeros outside the channel
     const long long seg0 = chunk0 - hist;
-    for (int u = tid * 4; u < xs_len; u += kFirThreads * 4) {
+    int u0 = tid * 4;
+    if (!MULTI && ALIGNED && seg0 >= 0 && seg0 + xs_len <= nn) {
+        // interior chunk of a long channel: unconditional loads, four in flight per thread
+        constexpr int kStep = kFirThreads * 4;
+        const float *xc = x + ch0 * n + seg0;
+        for (; u0 + 3 * kStep < xs_len; u0 += 4 * kStep) {
+            float4 v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const float4 *>(xc + u0 + i * kStep);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) *reinterpret_cast<float4 *>(xs + u0 + i * kStep) = v[i];
+        }
+    }
+    for (int u = u0; u < xs_len; u += kFirThreads * 4) {
         const int k = MULTI ? u / slot_len : 0, off = u - k * slot_len;  // slot_len is a multiple of 4: a float4 stays in its slot
         const size_t ch = ch0 + k;
         const long long g = seg0 + off;
