@@ -188,6 +188,21 @@ __global__ __launch_bounds__(kWave) void iir_batch_kernel(const float *__restric
             else run_row_partial<P, true>(row, static_cast<int>(n - t0), xh, vh, co);
         }
         __syncthreads();
+        if (ALIGNED && ch0 + kWave <= channels && t0 + kBt <= n) {  // full tile: LDS reads four at a time, no bounds tests
+            const float *src = tile + (lane / kLanesPerRow) * kBtPad + (lane % kLanesPerRow) * 4;
+            float *p = y + (ch0 + lane / kLanesPerRow) * n + t0 + (lane % kLanesPerRow) * 4;
+#pragma unroll
+            for (int it0 = 0; it0 < kBtIters; it0 += 4) {
+                float4 q[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) q[i] = *reinterpret_cast<const float4 *>(src + (it0 + i) * kRowsPerIter * kBtPad);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    store_stream_f4(p + static_cast<size_t>((it0 + i) * kRowsPerIter) * n, q[i].x, q[i].y, q[i].z, q[i].w);
+            }
+            __syncthreads();
+            continue;
+        }
 #pragma unroll
         for (int it = 0; it < kBtIters; ++it) {
             const size_t c = ch0 + it * kRowsPerIter + lane / kLanesPerRow;
@@ -405,8 +420,13 @@ __global__ __launch_bounds__(kSt) void iir_scan_kernel(const float *__restrict__
         if (MODE == SCAN_FUSED && tl > 0) return static_cast<size_t>(kTile) + static_cast<size_t>(tl - 1) * (kTile - warm) - warm;
         return static_cast<size_t>(tl) * kTile;
     };
-    constexpr int kPre = kTile / (kSt * 4);  // float4 loads per thread per tile = 8
+    constexpr int kPre = kTile / (kSt * 4);  // float4 loads per thread per tile = 16
     auto tile_load = [&](float4 (&pre)[kPre], size_t start) {
+        if (ALIGNED && start + kTile <= n) {  // whole tile inside the channel: no bounds tests between the loads
+#pragma unroll
+            for (int q = 0; q < kPre; ++q) pre[q] = load_stream_f4(xc + start + tid * 4 + q * kSt * 4);
+            return;
+        }
 #pragma unroll
         for (int q = 0; q < kPre; ++q) {
             const size_t g = start + static_cast<size_t>(tid * 4 + q * kSt * 4);
@@ -546,18 +566,35 @@ __global__ __launch_bounds__(kSt) void iir_scan_kernel(const float *__restrict__
     }
     __syncthreads();
 
-    for (int u = tid * 4; u < kTile; u += kSt * 4) {
-        const size_t g = start + u;
-        if (g < out_begin || g >= n) continue;
-        const float *src = xs + (u / kRow + 1) * kRowPad + (u % kRow);
-        if (ALIGNED && g + 3 < n) {
-            const float4 q = *reinterpret_cast<const float4 *>(src);
-            store_stream_f4(yc + g, q.x, q.y, q.z, q.w);
-        } else {
-            yc[g] = src[0];
-            if (g + 1 < n) yc[g + 1] = src[1];
-            if (g + 2 < n) yc[g + 2] = src[2];
-            if (g + 3 < n) yc[g + 3] = src[3];
+    if (ALIGNED && start + kTile <= n) {  // whole tile inside the channel: LDS reads four at a time, no bounds tests
+#pragma unroll
+        for (int q0 = 0; q0 < kPre; q0 += 4) {
+            float4 v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int u = tid * 4 + (q0 + i) * kSt * 4;
+                v[i] = *reinterpret_cast<const float4 *>(xs + (u / kRow + 1) * kRowPad + (u % kRow));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const size_t g = start + static_cast<size_t>(tid * 4 + (q0 + i) * kSt * 4);
+                if (g >= out_begin) store_stream_f4(yc + g, v[i].x, v[i].y, v[i].z, v[i].w);
+            }
+        }
+    } else {
+        for (int u = tid * 4; u < kTile; u += kSt * 4) {
+            const size_t g = start + u;
+            if (g < out_begin || g >= n) continue;
+            const float *src = xs + (u / kRow + 1) * kRowPad + (u % kRow);
+            if (ALIGNED && g + 3 < n) {
+                const float4 q = *reinterpret_cast<const float4 *>(src);
+                store_stream_f4(yc + g, q.x, q.y, q.z, q.w);
+            } else {
+                yc[g] = src[0];
+                if (g + 1 < n) yc[g + 1] = src[1];
+                if (g + 2 < n) yc[g + 2] = src[2];
+                if (g + 3 < n) yc[g + 3] = src[3];
+            }
         }
     }
     __syncthreads();  // the tile has been read out before the next one is staged
