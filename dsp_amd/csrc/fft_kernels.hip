@@ -77,10 +77,16 @@ __global__ __launch_bounds__(kThreads) void fft_lds_kernel(const void *__restric
     } else if (live) {
         if constexpr (REAL_IN) {
             const float *src = static_cast<const float *>(in_) + xf * in_stride;
+            if (n_in >= static_cast<size_t>(N)) {  // no zero padding: no bounds tests between the loads
 #pragma unroll
-            for (int m = 0; m < kPoints; ++m) {
-                const size_t i = lt + T * m;
-                r[m] = mk(i < n_in ? src[i] : 0.0f, 0.0f);
+                for (int m = 0; m < kPoints; ++m)  // short rows: a line is shared by several loads, keep it cached
+                    r[m] = mk(T >= 16 ? __builtin_nontemporal_load(src + lt + T * m) : src[lt + T * m], 0.0f);
+            } else {
+#pragma unroll
+                for (int m = 0; m < kPoints; ++m) {
+                    const size_t i = lt + T * m;
+                    r[m] = mk(i < n_in ? src[i] : 0.0f, 0.0f);
+                }
             }
         } else {
             const c32 *src = static_cast<const c32 *>(in_) + xf * N;
