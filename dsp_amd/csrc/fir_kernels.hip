@@ -354,7 +354,18 @@ __global__ __launch_bounds__(((1 << LOG2N) / kPoints) < 256 ? 256 : ((1 << LOG2N
 #pragma unroll
         for (int m = 0; m < kPoints; ++m)
             r[m] = mk(__builtin_nontemporal_load(pa + T * m), __builtin_nontemporal_load(pb + T * m));
-    } else {
+    } else if (!(hist && (in_a < hoff || in_b < hoff))) {
+        // ragged pair (a channel's last blocks, short channels): every load goes out, aimed at the channel's first
+        // sample when its own index is outside the signal, and is zeroed afterwards -- no branch between the loads
+#pragma unroll
+        for (int m = 0; m < kPoints; ++m) {
+            const long long ia = in_a + lt + T * m, ib = in_b + lt + T * m;
+            const bool oka = ia >= hoff && ia < nn, okb = ib >= hoff && ib < nn;
+            const float va = __builtin_nontemporal_load(xa + (oka ? ia : hoff));
+            const float vb = __builtin_nontemporal_load(xb + (okb ? ib : hoff));
+            r[m] = mk(oka ? va : 0.0f, okb ? vb : 0.0f);
+        }
+    } else {  // the first pair of a streamed chunk reaches into the carried history
 #pragma unroll
         for (int m = 0; m < kPoints; ++m) {
             const long long ia = in_a + lt + T * m, ib = in_b + lt + T * m;
