@@ -80,16 +80,53 @@ __global__ __launch_bounds__(kFirThreads) void fir_direct_kernel(const float *__
     // input segment [chunk0 - hist, chunk0 + S) of every slot's channel, zeros outside the channel
     const long long seg0 = chunk0 - hist;
     int u0 = tid * 4;
-    if (!MULTI && ALIGNED && seg0 >= 0 && seg0 + xs_len <= nn) {
-        // interior chunk of a long channel: unconditional loads, four in flight per thread
+    if (!MULTI && ALIGNED && (!prev || seg0 >= 0)) {
+        // long channel: four loads in flight per thread, no branch between them; a float4 outside the channel (n and
+        // seg0 are multiples of 4: wholly outside) is aimed at the channel's first sample and zeroed afterwards
         constexpr int kStep = kFirThreads * 4;
-        const float *xc = x + ch0 * n + seg0;
+        const float *xc = x + ch0 * n;
+        if (seg0 >= 0 && seg0 + xs_len <= nn) {  // interior chunk: nothing to clamp
+            for (; u0 + 3 * kStep < xs_len; u0 += 4 * kStep) {
+                float4 v[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const float4 *>(xc + seg0 + u0 + i * kStep);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) *reinterpret_cast<float4 *>(xs + u0 + i * kStep) = v[i];
+            }
+        }
         for (; u0 + 3 * kStep < xs_len; u0 += 4 * kStep) {
             float4 v[4];
+            bool ok[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const float4 *>(xc + u0 + i * kStep);
+            for (int i = 0; i < 4; ++i) {
+                const long long g = seg0 + u0 + i * kStep;
+                ok[i] = g >= 0 && g < nn;
+                v[i] = *reinterpret_cast<const float4 *>(xc + (ok[i] ? g : 0));
+            }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) *reinterpret_cast<float4 *>(xs + u0 + i * kStep) = v[i];
+            for (int i = 0; i < 4; ++i)
+                *reinterpret_cast<float4 *>(xs + u0 + i * kStep) = ok[i] ? v[i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
+    }
+    if (MULTI && ALIGNED && !prev) {
+        // short channels, one-shot: every float4 is wholly inside its channel or wholly outside (n, hist multiples of
+        // 4); outside ones are aimed at x[0] and zeroed afterwards, so four loads go out together without a branch
+        constexpr int kStep = kFirThreads * 4;
+        for (; u0 < xs_len; u0 += 4 * kStep) {
+            float4 v[4];
+            bool ok[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int u = u0 + i * kStep;
+                const int k = u / slot_len, off = u - k * slot_len;
+                const long long g = seg0 + off;
+                ok[i] = u < xs_len && ch0 + k < channels && g >= 0 && g < nn;
+                v[i] = *reinterpret_cast<const float4 *>(x + (ok[i] ? (ch0 + k) * n + g : 0));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (u0 + i * kStep < xs_len)
+                    *reinterpret_cast<float4 *>(xs + u0 + i * kStep) = ok[i] ? v[i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         }
     }
     for (int u = u0; u < xs_len; u += kFirThreads * 4) {
@@ -477,16 +514,32 @@ __global__ __launch_bounds__(kThreads) void moving_average_kernel(const float *_
     const float corr = ((npoints & 1) == 0 && npoints < nn) ? xc[npoints] : 0.0f;
 
     int u0 = tid * 4;
-    if (ALIGNED && seg0 >= 0 && seg0 + span <= nn) {
-        // interior tile: unconditional loads, four in flight per thread (a bounds branch around every load makes the
-        // compiler wait for each one before issuing the next)
+    if (ALIGNED) {
+        // four loads in flight per thread, no branch between them (a bounds branch around every load makes the compiler
+        // wait for each one before issuing the next).  n and seg0 are multiples of 4, so a float4 lies wholly inside
+        // the channel or wholly outside; outside ones are aimed at the channel's first sample and zeroed afterwards.
         constexpr int kStep = kThreads * 4;
+        if (seg0 >= 0 && seg0 + span <= nn) {  // interior tile: nothing to clamp
+            for (; u0 + 3 * kStep < span; u0 += 4 * kStep) {
+                float4 v[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = load_stream_f4(xc + seg0 + u0 + i * kStep);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) *reinterpret_cast<float4 *>(xs + ma_pad(u0 + i * kStep)) = v[i];
+            }
+        }
         for (; u0 + 3 * kStep < span; u0 += 4 * kStep) {
             float4 v[4];
+            bool ok[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = load_stream_f4(xc + seg0 + u0 + i * kStep);
+            for (int i = 0; i < 4; ++i) {
+                const long long g = seg0 + u0 + i * kStep;
+                ok[i] = g >= 0 && g < nn;
+                v[i] = load_stream_f4(xc + (ok[i] ? g : 0));
+            }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) *reinterpret_cast<float4 *>(xs + ma_pad(u0 + i * kStep)) = v[i];
+            for (int i = 0; i < 4; ++i)
+                *reinterpret_cast<float4 *>(xs + ma_pad(u0 + i * kStep)) = ok[i] ? v[i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         }
     }
     for (int u = u0; u < span; u += kThreads * 4) {
