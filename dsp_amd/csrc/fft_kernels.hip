@@ -48,21 +48,30 @@ __global__ __launch_bounds__(kThreads) void fft_lds_kernel(const void *__restric
     const size_t xf = tile * G + g;
     const bool live = xf < batch;
 
-    // Short transforms (T < 16 threads each): a thread's own points are only T*8 bytes apart from its
-    // neighbour's, so direct accesses would touch up to 64 lines per wave instruction.  The tile is contiguous
-    // in memory: move it with fully coalesced accesses and redistribute through the LDS image instead.
-    constexpr bool kStaged = T < 16;
+    // The tile is contiguous in memory and moves with 16-byte accesses (two points per lane, 1 KB per wave
+    // instruction), redistributed through the LDS image.  Short transforms (T < 16 threads each) need that anyway --
+    // a thread's own points are only T*8 bytes apart from its neighbour's, direct accesses would touch up to 64
+    // lines per wave instruction -- and for the long ones the wider accesses are worth more than the two extra LDS
+    // round trips cost (A/B on one box: N = 4096 369 -> 373, real input 485 -> 499 GSamples/s; N = 16 ... 128
+    // 367 -> 380 against 8-byte accesses).
+    constexpr bool kStaged = true;
     const size_t tile_points = (batch - tile * G < static_cast<size_t>(G) ? batch - tile * G : static_cast<size_t>(G)) * N;
 
     c32 r[kPoints];
     if constexpr (kStaged && !REAL_IN) {
         const c32 *src = static_cast<const c32 *>(in_) + tile * kTile;
         if (tile_points == static_cast<size_t>(kTile)) {  // full tile: sixteen unconditional loads in flight at once
-            c32 v[kPoints];
+            // 16 bytes (two points) per lane and load: a wave instruction covers 1 KB
+            float4 v[kPoints / 2];
 #pragma unroll
-            for (int m = 0; m < kPoints; ++m) v[m] = load_stream(src + tid + kThreads * m);
+            for (int m = 0; m < kPoints / 2; ++m)
+                v[m] = load_stream_f4(reinterpret_cast<const float *>(src + 2 * (tid + kThreads * m)));
 #pragma unroll
-            for (int m = 0; m < kPoints; ++m) lds[padded(tid + kThreads * m)] = v[m];
+            for (int m = 0; m < kPoints / 2; ++m) {
+                const int e = 2 * (tid + kThreads * m);  // even: e and e + 1 share a padding group
+                lds[padded(e)] = mk(v[m].x, v[m].y);
+                lds[padded(e) + 1] = mk(v[m].z, v[m].w);
+            }
         } else {
 #pragma unroll
             for (int m = 0; m < kPoints; ++m) {
@@ -112,7 +121,11 @@ __global__ __launch_bounds__(kThreads) void fft_lds_kernel(const void *__restric
         c32 *dst = out + tile * kTile;
         if (tile_points == static_cast<size_t>(kTile)) {
 #pragma unroll
-            for (int m = 0; m < kPoints; ++m) store_stream(dst + tid + kThreads * m, lds[padded(tid + kThreads * m)]);
+            for (int m = 0; m < kPoints / 2; ++m) {
+                const int e = 2 * (tid + kThreads * m);
+                const c32 p0 = lds[padded(e)], p1 = lds[padded(e) + 1];
+                store_stream_f4(reinterpret_cast<float *>(dst + e), p0.x, p0.y, p1.x, p1.y);
+            }
         } else {
 #pragma unroll
             for (int m = 0; m < kPoints; ++m) {
