@@ -346,6 +346,17 @@ __global__ __launch_bounds__(TH) void fft_column_kernel(const c32 *__restrict__ 
         __syncthreads();
         const size_t b0 = (tile % tiles_per_a) * C;
         c32 *base = out + a * (plan.out_a ? plan.out_a : L * plan.B) + b0 * plan.s_hi;
+        if ((plan.s_hi & 1) == 0 && (reinterpret_cast<uintptr_t>(base) & 15) == 0) {
+            // 16 bytes (two consecutive k of one column) per lane and store: a wave instruction writes 1 KB
+#pragma unroll
+            for (int m = 0; m < kPoints / 2; ++m) {
+                const int i = 2 * (tid + TH * m);
+                const int cc = i / L, k = i % L;  // L is even: k and k + 1 lie in the same column
+                const c32 p0 = lds[cc * (L + 1) + k], p1 = lds[cc * (L + 1) + k + 1];
+                store_stream_f4(reinterpret_cast<float *>(base + static_cast<size_t>(cc) * plan.s_hi + k), p0.x, p0.y, p1.x, p1.y);
+            }
+            return;
+        }
 #pragma unroll
         for (int m = 0; m < kPoints; ++m) {
             const int i = tid + TH * m;
