@@ -21,6 +21,7 @@ IIR_AUTO, IIR_BATCH, IIR_SCAN = 0, 1, 2
 # every symbol include/dsp_gpu.h declares (tests check the library exports all of them)
 EXPORTS = (
     "dsp_gpu_fft_batch",
+    "dsp_gpu_fft_batch_noalloc",
     "dsp_gpu_fft_real_batch",
     "dsp_gpu_convolve",
     "dsp_gpu_convolve_stream",
@@ -66,6 +67,8 @@ def lib() -> C.CDLL:
         L = C.CDLL(LIB_PATH)
         vp, sz, i = C.c_void_p, C.c_size_t, C.c_int
         L.dsp_gpu_fft_batch.argtypes = [vp, vp, i, sz, i, i, vp]
+        L.dsp_gpu_fft_batch_noalloc.argtypes = [vp, vp, i, sz, i, vp]
+        L.dsp_gpu_fft_batch_noalloc.restype = i
         L.dsp_gpu_fft_batch_timed.argtypes = [vp, vp, i, sz, i, i, C.POINTER(C.c_float), vp]
         L.dsp_gpu_fft_real_batch.argtypes = [vp, sz, sz, vp, i, sz, i, i, i, vp]
         L.dsp_gpu_convolve.argtypes = [vp, vp, sz, sz, vp, i, i, i, vp]

@@ -219,6 +219,15 @@ int dsp_gpu_fft_batch(const void *in, void *out, int log2n, size_t batch, int di
     return stage_out(out, bytes, s, hs);
 }
 
+int dsp_gpu_fft_batch_noalloc(const void *in, void *out, int log2n, size_t batch, int direction, void *stream) {
+    if (!in || !out) return fail(DSP_GPU_EINVAL, "dsp_gpu_fft_batch_noalloc: null buffer");
+    if (log2n < 1 || log2n > 21) return fail(DSP_GPU_EINVAL, "dsp_gpu_fft_batch_noalloc: log2n %d outside [1,21]", log2n);
+    if (direction != DSP_GPU_FORWARD && direction != DSP_GPU_INVERSE)
+        return fail(DSP_GPU_EINVAL, "dsp_gpu_fft_batch_noalloc: direction %d", direction);
+    return launch_fft_batch_noalloc(static_cast<const float2 *>(in), static_cast<float2 *>(out), log2n, batch, direction,
+                                    static_cast<hipStream_t>(stream));
+}
+
 int dsp_gpu_fft_batch_timed(const void *in, void *out, int log2n, size_t batch, int direction, int iters,
                             float *ms_per_launch, void *stream) {
     if (!in || !out || !ms_per_launch || iters < 1) return fail(DSP_GPU_EINVAL, "dsp_gpu_fft_batch_timed: bad argument");

@@ -64,6 +64,8 @@ void release_all_workspaces();
 
 // ---- kernel launchers (device pointers, asynchronous on `s`) --------------------------
 int launch_fft_batch(const float2 *in, float2 *out, int log2n, size_t batch, int direction, hipStream_t s);
+int launch_fft_batch_noalloc(const float2 *in, float2 *out, int log2n, size_t batch, int direction, hipStream_t s);
+size_t fft_noalloc_max_points();
 int launch_fft_real_batch(const float *in, size_t n_in, size_t in_stride, float2 *out, int log2n,
                           size_t batch, int direction, int shifted, hipStream_t s);
 int launch_fft_columns(const float2 *in, float2 *out, int log2n, size_t cols, int direction, hipStream_t s);

@@ -23,6 +23,7 @@
 //                              (ColumnPlan).  A transform of 2^13..2^16 points takes two such passes,
 //                              2^17..2^24 three, 2^25..2^30 four, all on one GPU.
 #include <algorithm>
+#include <mutex>
 
 #include "common.h"
 #include "fft_lds_core.h"
@@ -468,8 +469,11 @@ int launch_column(int log2l, const c32 *in, c32 *out, const ColumnPlan &plan, si
 // n_i, multiplies by W_{n_i * rest}^{k_i * r} (r = the index into n_{i+1} .. n_K, rest = their product; nothing on
 // the last step) and stores [n_{i+1} .. n_K][k_i][k_{i-1} .. k_1] -- after step K that is natural order.  The
 // passes ping-pong between `out` and one scratch buffer so that the input is never modified.
+// `fixed_scratch` != nullptr: the caller's buffer of at least batch * n points is the scratch (the allocation-free
+// entry point); otherwise the library's growing workspace.
 int launch_large(const c32 *in, c32 *out, int log2n, size_t batch, int direction, hipStream_t s,
-                 const float *real_in = nullptr, size_t real_n_in = 0, size_t real_stride = 0) {
+                 const float *real_in = nullptr, size_t real_n_in = 0, size_t real_stride = 0,
+                 c32 *fixed_scratch = nullptr) {
     const size_t n = static_cast<size_t>(1) << log2n;
     const int steps = log2n <= 16 ? 2 : (log2n <= 24 ? 3 : 4);
     int lg[4] = {0, 0, 0, 0};
@@ -477,9 +481,12 @@ int launch_large(const c32 *in, c32 *out, int log2n, size_t batch, int direction
         lg[i] = (left + (steps - i) - 1) / (steps - i);
         left -= lg[i];
     }
-    void *scratch_v = nullptr;
-    if (int rc = workspace(WS_SCRATCH_A, batch * n * sizeof(c32), &scratch_v)) return rc;
-    c32 *scratch = static_cast<c32 *>(scratch_v);
+    c32 *scratch = fixed_scratch;
+    if (!scratch) {
+        void *scratch_v = nullptr;
+        if (int rc = workspace(WS_SCRATCH_A, batch * n * sizeof(c32), &scratch_v)) return rc;
+        scratch = static_cast<c32 *>(scratch_v);
+    }
     // destination of pass i: the last one writes `out` and they alternate backwards; in place, the first pass
     // may not write what it reads, so the chain starts in scratch and a copy finishes it if it ends there
     const bool in_place = in == out && !real_in;
@@ -622,6 +629,51 @@ int launch_fft_real_batch(const float *in, size_t n_in, size_t in_stride, float2
     if (!shifted) return DSP_GPU_OK;
     hipLaunchKernelGGL(swap_halves_kernel, dim3(grid), dim3(kThreads), 0, s, out, n, total / 2);
     return check_launch("swap_halves_kernel");
+}
+
+// ---- the allocation-free form (dsp_gpu_fft_batch_noalloc) -------------------------------------------------------
+// Transforms of more than 2^14 points ping-pong between `out` and a scratch buffer.  Callers that cannot hipMalloc
+// (HIP graph capture, serving loops) get that buffer from this file-scope device array instead of the growing
+// workspace: 2^21 complex points = 16 MiB, held by every GPU the library runs on until the process ends.  The name
+// `scratch` is only the host-side handle of the symbol; its per-device address comes from hipGetSymbolAddress, once
+// per device, and only that pointer is handed to kernels.  Nothing in it has to start at zero (every pass overwrites
+// what the next one reads); all calls on one GPU share it, so calls that overlap on one GPU race.
+constexpr size_t kNoAllocPoints = static_cast<size_t>(1) << 21;
+static __device__ __align__(256) __attribute__((used)) unsigned char scratch[kNoAllocPoints * sizeof(c32)];
+
+namespace {
+constexpr int kNoAllocDevices = 64;
+std::mutex g_noalloc_mutex;
+c32 *g_noalloc_ptr[kNoAllocDevices] = {};
+
+int noalloc_scratch(c32 **ptr) {
+    int dev = 0;
+    DSPGPU_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= kNoAllocDevices) return fail(DSP_GPU_EUNSUPPORTED, "device index %d out of range", dev);
+    std::lock_guard<std::mutex> lock(g_noalloc_mutex);
+    if (!g_noalloc_ptr[dev]) {  // once per device, with that device current: every GPU holds its own copy of the array
+        void *p = nullptr;
+        DSPGPU_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        if (!p) return fail(DSP_GPU_EHIP, "hipGetSymbolAddress returned a null scratch address");
+        g_noalloc_ptr[dev] = static_cast<c32 *>(p);
+    }
+    *ptr = g_noalloc_ptr[dev];
+    return DSP_GPU_OK;
+}
+}  // namespace
+
+size_t fft_noalloc_max_points() { return kNoAllocPoints; }
+
+int launch_fft_batch_noalloc(const float2 *in_f2, float2 *out_f2, int log2n, size_t batch, int direction, hipStream_t s) {
+    if (batch == 0) return DSP_GPU_OK;
+    if (log2n <= 14) return launch_fft_batch(in_f2, out_f2, log2n, batch, direction, s);  // single pass: no scratch at all
+    if (batch > (kNoAllocPoints >> log2n))
+        return fail(DSP_GPU_EINVAL, "dsp_gpu_fft_batch_noalloc: %zu transforms of 2^%d points exceed the fixed scratch of 2^21 points",
+                    batch, log2n);
+    c32 *ptr = nullptr;
+    if (int rc = noalloc_scratch(&ptr)) return rc;
+    return launch_large(reinterpret_cast<const c32 *>(in_f2), reinterpret_cast<c32 *>(out_f2), log2n, batch, direction, s,
+                        nullptr, 0, 0, ptr);
 }
 
 }  // namespace dspgpu

@@ -72,6 +72,19 @@ int dsp_gpu_fft_batch(const void *in, void *out, int log2n, size_t batch, int di
                       void *stream);
 
 /*
+ * The allocation-free form of dsp_gpu_fft_batch.  NO COUNTERPART IN THE REFERENCE: it exists for callers that cannot
+ * allocate device memory -- code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  Same
+ * arithmetic and kernels as dsp_gpu_fft_batch on DEVICE pointers, asynchronous on `stream`, but the scratch buffer that
+ * transforms of more than 2^14 points ping-pong through is a fixed 16 MiB device array inside the library (2^21 complex
+ * points, held by every GPU the library runs on until the process ends) instead of the growing workspace, and the call
+ * makes no hipMalloc / hipFree.  1 <= log2n <= 21; for log2n >= 15, batch * 2^log2n <= 2^21 points (DSP_GPU_EINVAL
+ * beyond that; transforms of up to 2^14 points use no scratch and take any batch).  Every call on a GPU shares that
+ * GPU's array: calls that overlap on one GPU (two streams, two threads) race.  The first call on a device looks up the
+ * array's address (hipGetSymbolAddress) -- make it once outside a graph capture.
+ */
+int dsp_gpu_fft_batch_noalloc(const void *in, void *out, int log2n, size_t batch, int direction, void *stream);
+
+/*
  * Batched real-input FFT wrapper.  Replaces dsp::fft(first, last, c_out, nf) (fft.h:57-83):
  * each of `batch` rows holds n_in real samples (row stride in_stride floats); a row is
  * zero-padded to n = 2^ceil(log2 nf) (samples beyond n are ignored, as in the reference),
