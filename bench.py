@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--dist-exchange", default="torch", choices=["torch", "rccl"],
                     help="fft_dist only: all_to_all_single between the plan's phases, or dsp_gpu_fft_dist's own RCCL exchange")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="default fft run only: skip the FIR / IIR / moving-average workloads reported under `secondary`")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the CPU baseline sample")
     ap.add_argument("--cpu-threads", type=int, default=int(os.environ.get("OMP_NUM_THREADS", "0") or 0),
                     help="also time the reference on this many host threads (0/1: skip); default $OMP_NUM_THREADS")
@@ -52,6 +54,7 @@ def parse():
 # ----------------------------------------------------------------------------------------------
 # workloads: each returns (step_fn, units_per_step, meta)
 # ----------------------------------------------------------------------------------------------
+SECONDARY = ("fir_direct", "fir_os", "iir_batch", "iir_scan", "mavg")  # timed after the headline FFT in the default run
 SHARD = (0, 1)  # (rank, world) when --scaling strong channel-shards the one-GPU batch
 
 
@@ -271,48 +274,47 @@ def main():
     global SHARD
     if args.scaling == "strong":
         SHARD = (rank, world)
-    if args.workload == "fft_dist":
-        step, units, meta = make_fft_dist(torch, dev, world, rank, args.dist_exchange)
-    elif args.workload == "fft":
-        step, units, meta = make_fft(torch, dev, ops, rank)
-    elif args.workload in ("fir_direct", "fir_direct_valu", "fir_os"):
-        step, units, meta = make_fir(torch, dev, ops, rank, {"fir_direct": "direct", "fir_direct_valu": "direct_valu",
-                                                             "fir_os": "overlap_save"}[args.workload])
-    elif args.workload == "mavg":
-        step, units, meta = make_mavg(torch, dev, ops, rank)
-    else:
-        step, units, meta = make_iir(torch, dev, ops, rank, "batch" if args.workload == "iir_batch" else "scan")
 
     def barrier():
         if world > 1:
             dist.barrier()
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-
-    # The launches go to torch's current stream (ops passes its handle through the C ABI), so
-    # events recorded on that stream bracket exactly the kernels of the timed region.
-    stream = torch.cuda.current_stream(dev)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    e0.record(stream)
-    for _ in range(args.steps):
-        step()
-    e1.record(stream)
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    kernel_ms = e0.elapsed_time(e1) / args.steps
-
-    elapsed = multigpu.max_over_ranks(elapsed, dev)
-    all_units = multigpu.sum_over_ranks(float(units), dev)  # ranks may own unequal shares under strong scaling
-
-    if rank == 0:
-        total_units = all_units * args.steps
-        value = total_units / elapsed / 1e9
+    def measure(workload, steps, warmup):
+        """Warm up, then time exactly `steps` passes of one workload between barriers; returns the rank-0 record parts."""
+        if workload == "fft_dist":
+            step, units, meta = make_fft_dist(torch, dev, world, rank, args.dist_exchange)
+        elif workload == "fft":
+            step, units, meta = make_fft(torch, dev, ops, rank)
+        elif workload in ("fir_direct", "fir_direct_valu", "fir_os"):
+            step, units, meta = make_fir(torch, dev, ops, rank, {"fir_direct": "direct", "fir_direct_valu": "direct_valu",
+                                                                 "fir_os": "overlap_save"}[workload])
+        elif workload == "mavg":
+            step, units, meta = make_mavg(torch, dev, ops, rank)
+        else:
+            step, units, meta = make_iir(torch, dev, ops, rank, "batch" if workload == "iir_batch" else "scan")
+        for _ in range(warmup):
+            step()
+        torch.cuda.synchronize()
+        # The launches go to torch's current stream (ops passes its handle through the C ABI), so
+        # events recorded on that stream bracket exactly the kernels of the timed region.
+        stream = torch.cuda.current_stream(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        e0.record(stream)
+        for _ in range(steps):
+            step()
+        e1.record(stream)
+        torch.cuda.synchronize()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        kernel_ms = e0.elapsed_time(e1) / steps
+        elapsed = multigpu.max_over_ranks(elapsed, dev)
+        all_units = multigpu.sum_over_ranks(float(units), dev)  # ranks may own unequal shares under strong scaling
+        del step
+        torch.cuda.empty_cache()
+        value = all_units * steps / elapsed / 1e9
         launch_s = kernel_ms * 1e-3
         if meta["bound"] == "hbm":
             achieved = units * meta["alg_per_unit"] / launch_s / 1e9
@@ -322,18 +324,38 @@ def main():
             achieved = units * meta["alg_per_unit"] / launch_s / 1e12
             roof = {"bound": "mfma", "achieved": achieved, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": achieved / FP32_PEAK_TFLOPS}
-        roof.update({"traffic": measured_traffic(args.workload), "kernel": meta["kernel"],
+        roof.update({"traffic": measured_traffic(workload), "kernel": meta["kernel"],
                      "launch_ms": kernel_ms, "algorithmic": meta["alg_unit"]})
-        line = {"metric": meta["metric"], "value": value, "unit": meta["unit"], "n_gpus": world, "steps": args.steps,
-                "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-                "scaling": args.scaling, "vs_baseline": None, "dtype": meta["dtype"], "data": "synthetic",
-                "config": meta["config"], "roofline": roof}
-        if world == 1 and not args.no_cpu_baseline:
+        return {"metric": meta["metric"], "value": value, "unit": meta["unit"], "ms_per_step": elapsed / steps * 1e3,
+                "dtype": meta["dtype"], "config": meta["config"], "roofline": roof}
+
+    main_rec = measure(args.workload, args.steps, args.warmup)
+    # BASELINE.json's metric also names the FIR (GMAC/s) and IIR rates: the default run times those workloads too, at
+    # their full C3 / C4 sizes, with the same barriers and step count, and reports them beside the headline value
+    secondary = []
+    if args.workload == "fft" and not args.no_secondary:
+        for w in SECONDARY:
+            secondary.append((w, measure(w, args.steps, args.warmup)))
+
+    if rank == 0:
+        line = {"metric": main_rec["metric"], "value": main_rec["value"], "unit": main_rec["unit"], "n_gpus": world,
+                "steps": args.steps, "warmup": args.warmup, "ms_per_step": main_rec["ms_per_step"],
+                "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": main_rec["dtype"],
+                "data": "synthetic", "config": main_rec["config"], "roofline": main_rec["roofline"]}
+        cpu = world == 1 and not args.no_cpu_baseline
+        if cpu:
             line["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_seconds)
             if args.cpu_threads > 1:  # reported beside it, never the target (the roofline fraction is)
                 line["cpu_baseline_all_cores"] = cpu_baseline(args.workload, args.cpu_seconds / 2, args.cpu_threads)
             if args.workload == "fft":
                 line["cpu_baseline_f32"] = cpu_baseline("fft_f32", args.cpu_seconds / 4)
+        if secondary:
+            line["secondary"] = []
+            for w, rec in secondary:
+                rec = dict(rec, workload=w, steps=args.steps, warmup=args.warmup)
+                if cpu:
+                    rec["cpu_baseline"] = cpu_baseline(w, min(args.cpu_seconds / 4, 3.0))
+                line["secondary"].append(rec)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

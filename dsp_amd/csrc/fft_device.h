@@ -45,18 +45,24 @@ DSP_DEV c32 csub(c32 a, c32 b) { return a - b; }
 // Complex product in two packed instructions.  The swap and the negation ride on the op_sel / neg
 // modifiers (lo result: a.x*b.x then -a.y*b.y + lo; hi result: a.y*b.x then a.x*b.y + hi); written as
 // asm because the backend otherwise spends a v_xor and two v_mov per product on them.
+// Both instructions sit in ONE asm statement: between two statements hipcc pads a dependent use of an asm result
+// with `s_nop 0` (it cannot see that v_pk_mul_f32 writes whole registers), one issue slot per complex product.
 DSP_DEV c32 cmul(c32 a, c32 b) {
-    c32 t, r;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "v"(b));
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(a), "v"(b), "v"(t));
+    c32 r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]\n\t"
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]"
+        : "=&v"(r)
+        : "v"(a), "v"(b));
     return r;
 }
 
 // the same with a compile-time constant b held in a scalar register pair (no VGPRs, no v_mov)
 DSP_DEV c32 cmul_k(c32 a, c32 b) {
-    c32 t, r;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "s"(b));
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(a), "s"(b), "v"(t));
+    c32 r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]\n\t"
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]"
+        : "=&v"(r)
+        : "v"(a), "s"(b));
     return r;
 }
 

@@ -1,0 +1,139 @@
+// fft_wave_core.h -- a 4096-point transform owned by ONE wavefront (gfx950).
+//
+// 64 lanes x 64 register-resident points: 4096 = 64 x 64, two radix-64 passes done entirely in a lane's
+// registers, ONE twiddled step between them and ONE 64x64 transpose through a wave-private LDS image.  Against
+// the workgroup-level radix-16 transform (fft_lds_core.h: three passes, two twiddled steps, two exchanges behind
+// workgroup barriers) this is ~20 % fewer vector instructions per point (the twiddle work halves), half the LDS
+// traffic and no barrier at all -- a wave never waits for another wave.  The price is registers: 128 VGPRs of
+// data, so two waves per SIMD.  Used by the overlap-save FIR (fir_kernels.hip), which is bound by exactly the
+// instruction count and the exchanges.  Stands in for the butterfly loop of dsp::fft0 (reference fft.h:40-54);
+// SIGN = +1 is the reference's FORWARD (e^{+i 2 pi k n / N}, fft.h:22-29), nothing normalises.
+#pragma once
+
+#include "fft_device.h"
+
+namespace dspgpu {
+
+constexpr int kWavePoints = 64;                 // points per lane
+constexpr int kWaveN = 64 * kWavePoints;        // 4096 points per wave
+constexpr int kWaveRow = 65;                    // dwords per row of the transpose image: odd, so both the row-wise
+                                                // stores and the column-wise loads hit 32 distinct banks per half wave
+constexpr int kWaveLdsFloats = 64 * kWaveRow;   // one fp32 plane (re and im cross one after the other): 16,640 B
+
+constexpr float cos64(int q) {
+    constexpr float t[17] = {1.0f, 0.99518472667219693f, 0.98078528040323043f, 0.95694033573220882f,
+                             0.92387953251128674f, 0.88192126434835505f, 0.83146961230254524f, 0.77301045336273699f,
+                             0.70710678118654757f, 0.63439328416364549f, 0.55557023301960229f, 0.47139673682599781f,
+                             0.38268343236508984f, 0.29028467725446233f, 0.19509032201612833f, 0.09801714032956077f, 0.0f};
+    q &= 63;
+    return q <= 16 ? t[q] : (q <= 32 ? -t[32 - q] : (q <= 48 ? -t[q - 32] : t[64 - q]));
+}
+constexpr float sin64(int q) { return cos64(q + 48); }  // sin(x) = cos(x - pi/2)
+
+// multiply by exp(SIGN * 2 pi i * q / 64); q is a constant once the caller's loops are unrolled
+template <int SIGN>
+DSP_DEV c32 mul_w64(c32 a, int q) {
+    q &= 63;
+    if (q == 0) return a;
+    if (q == 16) return mul_i<SIGN>(a);
+    if (q == 32) return -a;
+    if (q == 48) return mul_i<-SIGN>(a);
+    // The constant is materialised in a scalar register pair right here (the empty volatile asm cannot be hoisted):
+    // left to itself the compiler keeps all ~60 distinct constants of the two directions live across the whole
+    // persistent loop and spills scalar registers.
+    c32 k = c32{cos64(q), SIGN * sin64(q)};
+    asm volatile("" : "+s"(k));
+    return cmul_k(a, k);
+}
+
+// 64 = 16 x 4: n = 4*n1 + n2, k = k1 + 16*k2.  Natural order in and out.
+template <int SIGN>
+struct Dft<64, SIGN> {
+    static DSP_DEV void run(c32 (&v)[64]) {
+#pragma unroll
+        for (int n2 = 0; n2 < 4; ++n2) {  // A[k1][n2] = sum_n1 v[4 n1 + n2] W16^{n1 k1}, left at v[4 k1 + n2]
+            c32 t[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) t[i] = v[4 * i + n2];
+            Dft<16, SIGN>::run(t);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[4 * i + n2] = t[i];
+        }
+#pragma unroll
+        for (int k1 = 1; k1 < 16; ++k1) {
+#pragma unroll
+            for (int n2 = 1; n2 < 4; ++n2) v[4 * k1 + n2] = mul_w64<SIGN>(v[4 * k1 + n2], n2 * k1);
+        }
+#pragma unroll
+        for (int k1 = 0; k1 < 16; ++k1) dft4<SIGN>(v[4 * k1], v[4 * k1 + 1], v[4 * k1 + 2], v[4 * k1 + 3]);
+        c32 o[64];  // X[k1 + 16 k2] sits at v[4 k1 + k2]: a renaming, no instruction
+#pragma unroll
+        for (int k1 = 0; k1 < 16; ++k1) {
+#pragma unroll
+            for (int k2 = 0; k2 < 4; ++k2) o[k1 + 16 * k2] = v[4 * k1 + k2];
+        }
+#pragma unroll
+        for (int i = 0; i < 64; ++i) v[i] = o[i];
+    }
+};
+
+// Lane l holds r[j] = M[j][l]; afterwards r[j] = M[l][j].  `img` is this wave's private plane of kWaveLdsFloats
+// floats.  A wave's LDS instructions execute in order, so the loads see the stores of every lane without any
+// hardware barrier; the wavefront-scope fences only keep the compiler from reordering across them.
+DSP_DEV void wave_transpose(c32 (&r)[kWavePoints], float *img, int lane) {
+    float *wr = img + lane;             // row j, column lane:  wr[j * kWaveRow]
+    float *rd = img + lane * kWaveRow;  // row lane, column j:  rd[j]
+#pragma unroll
+    for (int j = 0; j < kWavePoints; ++j) wr[j * kWaveRow] = r[j].x;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int j = 0; j < kWavePoints; ++j) r[j].x = rd[j];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int j = 0; j < kWavePoints; ++j) wr[j * kWaveRow] = r[j].y;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int j = 0; j < kWavePoints; ++j) r[j].y = rd[j];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// In: r[j] = x[lane + 64 j].  Out: r[j] = X[lane + 64 j], X[k] = sum_n x[n] exp(SIGN 2 pi i n k / 4096).
+//   n = 64 n1 + n2, k = k1 + 64 k2:
+//   X[k1 + 64 k2] = sum_n2 W64^{n2 k2} ( W4096^{n2 k1} sum_n1 x[64 n1 + n2] W64^{n1 k1} )
+// pass 1 over n1 in the registers of lane n2; twiddle W4096^{lane * k1}; transpose; pass 2 over n2 in lane k1.
+template <int SIGN>
+DSP_DEV void fft4096_wave(c32 (&r)[kWavePoints], float *img, int lane) {
+    Dft<64, SIGN>::run(r);
+    {
+        // W^{lane * k1}, k1 = 8a + b:  (W^{8 lane})^a * (W^{lane})^b -- one sincospif, two short product trees
+        const c32 w = unit_root<SIGN>(static_cast<unsigned>(lane), 12);
+        c32 pb[8], pa[8];
+        pb[1] = w;
+#pragma unroll
+        for (int t = 2; t < 8; ++t) pb[t] = cmul(pb[t >> 1], pb[t - (t >> 1)]);
+        pa[1] = cmul(pb[4], pb[4]);
+#pragma unroll
+        for (int t = 2; t < 8; ++t) pa[t] = cmul(pa[t >> 1], pa[t - (t >> 1)]);
+#pragma unroll
+        for (int a = 0; a < 8; ++a) {
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                if (a == 0 && b == 0) continue;
+                const c32 tw = a == 0 ? pb[b] : (b == 0 ? pa[a] : cmul(pa[a], pb[b]));
+                r[8 * a + b] = cmul(r[8 * a + b], tw);
+            }
+        }
+    }
+    wave_transpose(r, img, lane);
+    Dft<64, SIGN>::run(r);
+}
+
+}  // namespace dspgpu

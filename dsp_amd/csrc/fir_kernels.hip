@@ -25,9 +25,11 @@
 //   moving_average_kernel    windows summed from 16-sample partial sums held in LDS (no running
 //                            sum along the signal, so no accumulated drift).
 #include <algorithm>
+#include <cstdlib>
 
 #include "common.h"
 #include "fft_lds_core.h"
+#include "fft_wave_core.h"
 
 namespace dspgpu {
 namespace {
@@ -349,7 +351,7 @@ template <int LOG2N>
 __global__ __launch_bounds__(((1 << LOG2N) / kPoints) < 256 ? 256 : ((1 << LOG2N) / kPoints)) void fir_overlap_save_kernel(
     const float *__restrict__ x, float *__restrict__ y, size_t n, const c32 *__restrict__ hspec, int ntaps,
     unsigned blocks_per_channel, size_t total_blocks, size_t tiles, size_t wg_tiles, size_t chunk,
-    const float *__restrict__ hist, int zero_head, OsExtra ex) {
+    const float *__restrict__ hist, int zero_head, OsExtra ex, int hop) {
     constexpr int kOsN = 1 << LOG2N;    // block (transform) length
     constexpr int T = kOsN / kPoints;   // threads per transform
     constexpr int G = T < 256 ? 256 / T : 1;  // transforms (block pairs) per workgroup
@@ -367,7 +369,12 @@ __global__ __launch_bounds__(((1 << LOG2N) / kPoints) < 256 ? 256 : ((1 << LOG2N
     const size_t ch_a = qa / blocks_per_channel, ch_b = has_b ? qb / blocks_per_channel : ch_a;
     const unsigned blk_a = static_cast<unsigned>(qa % blocks_per_channel), blk_b = static_cast<unsigned>(qb % blocks_per_channel);
     const long long order = ntaps - 1;
-    const long long L = kOsN - order;
+    // Block b reads inputs [b*L, b*L + N) and keeps its outputs k >= N - L (block 0: k >= order).  L <= N - order; the
+    // launcher rounds it down to a multiple of 64 samples where that costs next to nothing, so that on channels whose
+    // length is a multiple of 64 every block starts on a 256-byte boundary and a wave's stores are whole 128-byte
+    // lines (with L = N - order = 3586 the same kernel's stores ran at 2.7 instead of 4.3 TB/s).
+    const long long L = hop;
+    const long long keep0 = kOsN - L;
     // streaming form: the blocks run over the virtual signal history ++ x (hoff = ntaps-1 samples of
     // history in front), so every output of x is kept; one-shot form: hoff = 0 and y[0, order) = 0
     const long long hoff = (hist || ex.zero_hist) ? order : 0;
@@ -428,23 +435,24 @@ __global__ __launch_bounds__(((1 << LOG2N) / kPoints) < 256 ? 256 : ((1 << LOG2N
         if (has_b && blk_b == 0)
             for (long long j = lt; j < order && j < nn; j += T) yb[j] = 0.0f;
     }
+    // first kept output of each block: what lies before it is the wrapped (circular) part or the previous block's
+    const long long first_a = blk_a == 0 ? order : keep0, first_b = blk_b == 0 ? order : keep0;
     if (ex.accumulate) {  // partitioned form: this segment's contribution on top of the earlier ones
 #pragma unroll
         for (int m = 0; m < kPoints; ++m) {
             const long long k = lt + T * m;
-            if (k < order) continue;
             const long long ja = in_a + k, jb = in_b + k;
-            if (ja < nn) ya[ja] += r[m].x;
-            if (jb < nn) yb[jb] += r[m].y;
+            if (k >= first_a && ja < nn) ya[ja] += r[m].x;
+            if (k >= first_b && jb < nn) yb[jb] += r[m].y;
         }
         return;
     }
-    if (interior) {  // every kept output is in range and past the zero head
+    if (interior && blk_a != 0 && blk_b != 0) {  // every kept output is in range and past the zero head
         float *pa = ya + in_a + lt, *pb = yb + in_b + lt;
-        const int ord = static_cast<int>(order);
+        const int k0 = static_cast<int>(keep0);
 #pragma unroll
         for (int m = 0; m < kPoints; ++m) {
-            if (lt + T * m < ord) continue;  // wrapped (circular) part of the block
+            if (lt + T * m < k0) continue;
             __builtin_nontemporal_store(r[m].x, pa + T * m);
             __builtin_nontemporal_store(r[m].y, pb + T * m);
         }
@@ -453,11 +461,155 @@ __global__ __launch_bounds__(((1 << LOG2N) / kPoints) < 256 ? 256 : ((1 << LOG2N
 #pragma unroll
     for (int m = 0; m < kPoints; ++m) {
         const long long k = lt + T * m;
-        if (k < order) continue;  // wrapped (circular) part of the block
         const long long ja = in_a + k, jb = in_b + k;
         // streaming: outputs before the stream's first full window stay zero like the one-shot head
-        if (ja < nn) __builtin_nontemporal_store(ja - hoff < zero_head ? 0.0f : r[m].x, ya + ja);
-        if (jb < nn) __builtin_nontemporal_store(jb - hoff < zero_head ? 0.0f : r[m].y, yb + jb);
+        if (k >= first_a && ja < nn) __builtin_nontemporal_store(ja - hoff < zero_head ? 0.0f : r[m].x, ya + ja);
+        if (k >= first_b && jb < nn) __builtin_nontemporal_store(jb - hoff < zero_head ? 0.0f : r[m].y, yb + jb);
+    }
+}
+
+// The same overlap-save step with ONE WAVE per block pair (fft_wave_core.h): 64 lanes x 64 points, two radix-64
+// passes per transform, one wave-private transpose each way, no workgroup barrier after the set-up.  A workgroup is
+// eight independent persistent waves (two per SIMD: 128 of the <= 256 VGPRs hold the points) that share only the tap
+// spectrum: taps are real, so H[4096 - k] = conj(H[k]) and half of it (2049 bins, pre-scaled by 1/4096) sits in LDS.
+// Long signals only (4096-point blocks, at least kOsWaveMinTiles block pairs): one wave walks a pair in ~10 us, so
+// few pairs are better off spread over 256 threads each (fir_overlap_save_kernel).
+constexpr int kOsWaveThreads = 512;
+constexpr int kOsWaveWaves = kOsWaveThreads / 64;
+constexpr int kOsWaveHalf = kWaveN / 2 + 1;                      // spectrum bins kept in LDS
+constexpr int kOsWaveHalfPad = (kOsWaveHalf + 7) & ~7;
+constexpr size_t kOsWaveLdsBytes = kOsWaveHalfPad * sizeof(c32) + kOsWaveWaves * kWaveLdsFloats * sizeof(float);
+constexpr size_t kOsWaveMinTiles = 4096;
+
+// a * conj(b) in two packed instructions (see cmul)
+DSP_DEV c32 cmul_conj(c32 a, c32 b) {
+    c32 r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]\n\t"
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]"
+        : "=&v"(r)
+        : "v"(a), "v"(b));
+    return r;
+}
+
+__global__ __launch_bounds__(kOsWaveThreads) void fir_os_wave_kernel(
+    const float *__restrict__ x, float *__restrict__ y, size_t n, const c32 *__restrict__ hspec, int ntaps,
+    unsigned blocks_per_channel, size_t total_blocks, size_t tiles, size_t chunk, const float *__restrict__ hist,
+    int zero_head, int hop) {
+    constexpr int T = 64, P = kWavePoints;
+    extern __shared__ __attribute__((aligned(16))) unsigned char os_wave_lds[];
+    c32 *hs = reinterpret_cast<c32 *>(os_wave_lds);
+    const int lane = static_cast<int>(threadIdx.x) & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
+    float *img = reinterpret_cast<float *>(os_wave_lds + kOsWaveHalfPad * sizeof(c32)) + wave * kWaveLdsFloats;
+    constexpr float scale = 1.0f / kWaveN;  // the 1/N of the inverse transform rides the spectrum
+    for (int i = threadIdx.x; i < kOsWaveHalf; i += kOsWaveThreads) {
+        const c32 h = hspec[i];
+        hs[i] = mk(h.x * scale, h.y * scale);
+    }
+    __syncthreads();  // the only workgroup barrier: from here on every wave runs on its own
+
+    const long long order = ntaps - 1;
+    const long long L = hop;                  // see fir_overlap_save_kernel: a multiple of 64 where possible
+    const long long keep0 = kWaveN - L;       // first kept output of a block (block 0: order)
+    const long long hoff = hist ? order : 0;  // streaming form: blocks run over history ++ x
+    const long long nn = static_cast<long long>(n) + hoff;
+    // each XCD streams one contiguous range of block pairs; its waves stride through it
+    const size_t xcd = blockIdx.x & 7u;
+    const size_t waves_per_xcd = static_cast<size_t>(gridDim.x >> 3) * kOsWaveWaves;
+    const c32 *hlo = hs + lane;                  // H[lane + 64 m],         m < 32
+    const c32 *hhi = hs + (kWaveN / 2 - lane);   // H[4096 - (lane + 64 m)], m >= 32:  hhi[-64 (m - 32)]
+    for (size_t t = static_cast<size_t>(blockIdx.x >> 3) * kOsWaveWaves + wave; t < chunk; t += waves_per_xcd) {
+        const size_t tile = xcd * chunk + t;
+        if (tile >= tiles) break;
+        // the two real blocks riding one complex transform are consecutive entries of the flattened (channel, block)
+        // list: with an odd block count per channel a pair straddles two channels
+        const size_t qa = 2 * tile, qb = qa + 1;
+        const bool has_b = qb < total_blocks;
+        const size_t ch_a = qa / blocks_per_channel, ch_b = has_b ? qb / blocks_per_channel : ch_a;
+        const unsigned blk_a = static_cast<unsigned>(qa % blocks_per_channel), blk_b = static_cast<unsigned>(qb % blocks_per_channel);
+        const float *xa = x + ch_a * n - hoff;  // xa[v] valid for v >= hoff
+        const float *xb = x + ch_b * n - hoff;
+        float *ya = y + ch_a * n - hoff;
+        float *yb = y + ch_b * n - hoff;
+        const float *ha = hist ? hist + ch_a * order : nullptr;
+        const float *hb = hist ? hist + ch_b * order : nullptr;
+        const long long in_a = static_cast<long long>(blk_a) * L;
+        const long long in_b = has_b ? static_cast<long long>(blk_b) * L : nn;  // a missing block: nothing loaded, nothing stored
+        const bool interior = in_a >= hoff && in_a + kWaveN <= nn && in_b >= hoff && in_b + kWaveN <= nn;
+
+        c32 r[P];
+        if (interior) {
+            const float *pa = xa + in_a + lane, *pb = xb + in_b + lane;
+#pragma unroll
+            for (int m = 0; m < P; ++m)
+                r[m] = mk(__builtin_nontemporal_load(pa + T * m), __builtin_nontemporal_load(pb + T * m));
+        } else {
+            // ragged pair (a channel's last blocks) or the first pair of a streamed chunk, which reaches into the carried
+            // history: rare, so the bounds handling runs as rolled loops that park the samples in the wave's LDS image
+            // (a lane reads back only what it wrote itself) instead of 128 unrolled guarded loads
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const float *xs = half ? xb : xa, *hp = half ? hb : ha;
+                const long long in0 = (half ? in_b : in_a) + lane;
+#pragma unroll 1
+                for (int m = 0; m < P; ++m) {
+                    const long long i = in0 + T * m;
+                    float v = 0.0f;
+                    if (i < nn) v = i >= hoff ? xs[i] : hp[i];
+                    img[m * kWaveRow + lane] = v;
+                }
+#pragma unroll
+                for (int m = 0; m < P; ++m) {
+                    if (half) r[m].y = img[m * kWaveRow + lane];
+                    else r[m].x = img[m * kWaveRow + lane];
+                }
+            }
+        }
+        fft4096_wave<+1>(r, img, lane);
+#pragma unroll
+        for (int m = 0; m < P; ++m) {  // bin k = lane + 64 m
+            if (m < P / 2) r[m] = cmul(r[m], hlo[T * m]);
+            else r[m] = cmul_conj(r[m], hhi[-T * (m - P / 2)]);
+        }
+        fft4096_wave<-1>(r, img, lane);
+
+        if (hoff == 0) {  // filter.h:126,133: the first `order` outputs of a channel stay zero
+            if (blk_a == 0)
+                for (long long j = lane; j < order && j < nn; j += T) ya[j] = 0.0f;
+            if (has_b && blk_b == 0)
+                for (long long j = lane; j < order && j < nn; j += T) yb[j] = 0.0f;
+        }
+        if (interior && blk_a != 0 && blk_b != 0) {  // every kept output is in range and past the zero head
+            float *pa = ya + in_a + lane, *pb = yb + in_b + lane;
+            // rows below m0 lie wholly in the dropped part of the block, row m0 partly (not at all with an aligned hop):
+            // wave-uniform tests, so that no per-row lane mask is kept in scalar registers across the loop
+            int m0 = static_cast<int>(keep0) / T, l0 = static_cast<int>(keep0) % T;
+            asm volatile("" : "+s"(m0), "+s"(l0));  // not loop invariants: 64 hoisted lane masks would spill scalar registers
+#pragma unroll
+            for (int m = 0; m < P; ++m) {
+                if (m < m0) continue;
+                if (m == m0 && lane < l0) continue;
+                __builtin_nontemporal_store(r[m].x, pa + T * m);
+                __builtin_nontemporal_store(r[m].y, pb + T * m);
+            }
+            continue;
+        }
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {  // rare: rolled, through the LDS image like the loads
+#pragma unroll
+            for (int m = 0; m < P; ++m) img[m * kWaveRow + lane] = half ? r[m].y : r[m].x;
+            float *ys = half ? yb : ya;
+            const long long in0 = half ? in_b : in_a;
+            const long long first = (half ? blk_b : blk_a) == 0 ? order : keep0;
+#pragma unroll 1
+            for (int m = 0; m < P; ++m) {
+                const long long k = lane + T * m;
+                if (k < first) continue;  // wrapped (circular) part of the block, or the previous block's outputs
+                const long long j = in0 + k;
+                // streaming: outputs before the stream's first full window stay zero like the one-shot head
+                if (j < nn) ys[j] = j - hoff < zero_head ? 0.0f : img[m * kWaveRow + lane];
+            }
+        }
     }
 }
 
@@ -701,18 +853,49 @@ int launch_fir_spectrum(const float *d_taps, int ntaps, float2 *d_hspec_f2, int 
 }
 
 namespace {
+// Block pairs from which the one-wave-per-pair kernel takes over.  DSP_GPU_OS_WAVE_MIN_TILES overrides it (read per
+// call): 1 sends every 4096-point-block call to the wave kernel, a huge value none -- for A/B runs and for parity
+// tests that exercise both kernels on small inputs.
+size_t os_wave_min_tiles() {
+    const char *e = getenv("DSP_GPU_OS_WAVE_MIN_TILES");
+    if (e && *e) return static_cast<size_t>(strtoull(e, nullptr, 10));
+    return kOsWaveMinTiles;
+}
+
 int launch_os(const float *x, float *y, size_t channels, size_t n, const c32 *d_hspec, int ntaps, const float *hist,
               int zero_head, const OsExtra &ex, int log2n, hipStream_t s) {
     const long long order = ntaps - 1;
     const long long kOsN = 1ll << log2n;
-    const long long L = kOsN - order;
+    // hop between blocks: N - order at most; one-shot calls round it down to a multiple of 64 samples when that costs
+    // at most 1/32 of it (block starts, and with them every wave's loads and stores, then sit on 256-byte boundaries)
+    long long L = kOsN - order;
+    if (!hist && !ex.zero_hist && (L & 63) != 0 && (L & ~63ll) >= 64 && (L & 63) * 32 <= L) L &= ~63ll;
     const long long nv = static_cast<long long>(n) + ((hist || ex.zero_hist) ? order : 0);  // length of the (virtual) signal
     const long long valid = nv > order ? nv - order : 0;
-    long long nblocks = (valid + L - 1) / L;
-    if (nblocks < 1) nblocks = 1;  // block 0 also zero-fills y[0, order)
+    // block 0 delivers N - order outputs, every later block L
+    long long nblocks = valid > kOsN - order ? 1 + (valid - (kOsN - order) + L - 1) / L : 1;  // block 0 also zero-fills y[0, order)
+    const int hop = static_cast<int>(L);
     const unsigned bpc = static_cast<unsigned>(nblocks);
     const size_t total_blocks = channels * static_cast<size_t>(nblocks);
     const size_t tiles = (total_blocks + 1) / 2;  // two real blocks per complex transform, across channels if need be
+    if (log2n == 12 && tiles >= os_wave_min_tiles() && !ex.accumulate && !ex.zero_hist && ex.stride == n && ex.yoff == 0) {
+        // long signals: one wave per block pair, persistent workgroups (one per CU: its LDS fills the CU)
+        static const int cus = [] {
+            int dev = 0, v = 256;
+            if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev);
+            return v;
+        }();
+        const size_t chunkw = (tiles + 7) / 8;
+        size_t wgs = (static_cast<size_t>(cus) + 7) / 8 * 8;
+        wgs = std::min(wgs, (chunkw + kOsWaveWaves - 1) / kOsWaveWaves * 8);
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(fir_os_wave_kernel),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                           static_cast<int>(kOsWaveLdsBytes));
+        if (attr != hipSuccess) return fail(DSP_GPU_EHIP, "fir_os_wave_kernel: LDS attribute: %s", hipGetErrorString(attr));
+        hipLaunchKernelGGL(fir_os_wave_kernel, dim3(static_cast<unsigned>(wgs)), dim3(kOsWaveThreads), kOsWaveLdsBytes, s, x, y, n,
+                           d_hspec, ntaps, bpc, total_blocks, tiles, chunkw, hist, zero_head, hop);
+        return check_launch("fir_os_wave_kernel");
+    }
     const size_t per_wg = kOsN < 4096 ? static_cast<size_t>(4096 / kOsN) : 1;  // transforms per workgroup
     const size_t wg_tiles = (tiles + per_wg - 1) / per_wg;
     const size_t chunk = (wg_tiles + 7) / 8;
@@ -722,7 +905,7 @@ int launch_os(const float *x, float *y, size_t channels, size_t n, const c32 *d_
     const dim3 grid(static_cast<unsigned>(8 * chunk));
 #define DSPGPU_OS_LAUNCH(LOG2N, THREADS)                                                                               \
     hipLaunchKernelGGL(fir_overlap_save_kernel<LOG2N>, grid, dim3(THREADS), lds_bytes, s, x, y, n, d_hspec, ntaps, bpc, \
-                       total_blocks, tiles, wg_tiles, chunk, hist, zero_head, ex)
+                       total_blocks, tiles, wg_tiles, chunk, hist, zero_head, ex, hop)
     switch (log2n) {
     case 8: DSPGPU_OS_LAUNCH(8, 256); break;
     case 9: DSPGPU_OS_LAUNCH(9, 256); break;
