@@ -343,6 +343,8 @@ struct OsExtra {
     size_t yoff;     // output j is stored at y[ch*stride + yoff + j]
     int accumulate;  // y += result instead of y = result
     int zero_hist;   // streaming form over an all-zero history (no `hist` buffer)
+    int edge_pairs;  // the grid walks only the pairs holding a channel's first or last block: workgroup 2c -> the pair of
+                     // channel c's block 0, 2c + 1 -> the pair of its last block (what fir_os_wave_kernel leaves out)
 };
 
 // Workgroup: 256 threads (1,024 for 16384-point blocks); a transform takes T = N/16 of them, so blocks of 256 ... 2,048
@@ -358,7 +360,9 @@ __global__ __launch_bounds__(((1 << LOG2N) / kPoints) < 256 ? 256 : ((1 << LOG2N
     extern __shared__ __attribute__((aligned(16))) c32 lds[];
     const int lt = static_cast<int>(threadIdx.x) % T, grp = static_cast<int>(threadIdx.x) / T;
     const int base = grp * kOsN;
-    const size_t wtile = xcd_tile_of(blockIdx.x, chunk);  // each XCD streams a contiguous range of block pairs
+    size_t wtile = xcd_tile_of(blockIdx.x, chunk);  // each XCD streams a contiguous range of block pairs
+    if (ex.edge_pairs)  // G == 1 here (4096-point blocks)
+        wtile = (static_cast<size_t>(blockIdx.x >> 1) * blocks_per_channel + ((blockIdx.x & 1u) ? blocks_per_channel - 1 : 0)) >> 1;
     if (wtile >= wg_tiles) return;
     const size_t tile = wtile * G + grp;
     const bool has_a = tile < tiles;  // a workgroup's last transforms may have no pair left: they idle through the barriers
@@ -470,11 +474,19 @@ __global__ __launch_bounds__(((1 << LOG2N) / kPoints) < 256 ? 256 : ((1 << LOG2N
 
 // The same overlap-save step with ONE WAVE per block pair (fft_wave_core.h): 64 lanes x 64 points, two radix-64
 // passes per transform, one wave-private transpose each way, no workgroup barrier after the set-up.  A workgroup is
-// eight independent persistent waves (two per SIMD: 128 of the <= 256 VGPRs hold the points) that share only the tap
-// spectrum: taps are real, so H[4096 - k] = conj(H[k]) and half of it (2049 bins, pre-scaled by 1/4096) sits in LDS.
-// Long signals only (4096-point blocks, at least kOsWaveMinTiles block pairs): one wave walks a pair in ~10 us, so
-// few pairs are better off spread over 256 threads each (fir_overlap_save_kernel).
-constexpr int kOsWaveThreads = 512;
+// four independent persistent waves, ONE PER SIMD (measured: two per SIMD transform slower, 1.68 against 1.50 ms of
+// pure arithmetic on C3, and leave no registers for what follows), sharing only the tap spectrum: taps are real, so
+// H[4096 - k] = conj(H[k]) and half of it (2049 bins, pre-scaled by 1/4096) sits in LDS.
+//
+// Software pipeline.  With one wave per SIMD nothing else hides HBM latency, so the NEXT pair's 2 x 4096 samples are
+// fetched while the current pair is transformed -- into the 128 accumulator registers (AGPRs) the wave does not use
+// otherwise, by asm loads the compiler knows nothing about: it never sees a pending value, because every use sits
+// behind the asm wait statement that names all 128 registers.  vmcnt counts loads and stores together, in order, and
+// the stores of the current pair are issued AFTER the prefetch; they are therefore 16-byte stores (re-laid out through
+// the wave's LDS image), few enough (<= 30) for `s_waitcnt vmcnt(#stores)` to wait for the prefetch alone.
+// One-shot calls on long signals only (4096-point blocks, >= kOsWaveMinTiles block pairs, hop a multiple of 256, n a
+// multiple of 4): one wave walks a pair in ~10 us, so few pairs are better off spread over 256 threads each.
+constexpr int kOsWaveThreads = 256;
 constexpr int kOsWaveWaves = kOsWaveThreads / 64;
 constexpr int kOsWaveHalf = kWaveN / 2 + 1;                      // spectrum bins kept in LDS
 constexpr int kOsWaveHalfPad = (kOsWaveHalf + 7) & ~7;
@@ -491,11 +503,31 @@ DSP_DEV c32 cmul_conj(c32 a, c32 b) {
     return r;
 }
 
+// dword loads into AGPRs, 16 rows of 64 samples per base pointer (the immediate offset reaches 4 KB)
+#define OSW_LOAD(dst, base, off) asm volatile("global_load_dword %0, %1, off offset:" #off " nt" : "=a"(dst) : "v"(base))
+#define OSW_ROW16(arr, k, base)                                                                                          \
+    OSW_LOAD(arr[16 * k + 0], base, 0); OSW_LOAD(arr[16 * k + 1], base, 256); OSW_LOAD(arr[16 * k + 2], base, 512);       \
+    OSW_LOAD(arr[16 * k + 3], base, 768); OSW_LOAD(arr[16 * k + 4], base, 1024); OSW_LOAD(arr[16 * k + 5], base, 1280);   \
+    OSW_LOAD(arr[16 * k + 6], base, 1536); OSW_LOAD(arr[16 * k + 7], base, 1792); OSW_LOAD(arr[16 * k + 8], base, 2048);  \
+    OSW_LOAD(arr[16 * k + 9], base, 2304); OSW_LOAD(arr[16 * k + 10], base, 2560); OSW_LOAD(arr[16 * k + 11], base, 2816); \
+    OSW_LOAD(arr[16 * k + 12], base, 3072); OSW_LOAD(arr[16 * k + 13], base, 3328); OSW_LOAD(arr[16 * k + 14], base, 3584); \
+    OSW_LOAD(arr[16 * k + 15], base, 3840)
+// ties 16 registers to the (volatile, hence ordered) wait in front: no use of them can move above it
+#define OSW_TIE16(arr, k)                                                                                              \
+    asm volatile("" : "+a"(arr[16 * k + 0]), "+a"(arr[16 * k + 1]), "+a"(arr[16 * k + 2]), "+a"(arr[16 * k + 3]),        \
+                 "+a"(arr[16 * k + 4]), "+a"(arr[16 * k + 5]), "+a"(arr[16 * k + 6]), "+a"(arr[16 * k + 7]),            \
+                 "+a"(arr[16 * k + 8]), "+a"(arr[16 * k + 9]), "+a"(arr[16 * k + 10]), "+a"(arr[16 * k + 11]),          \
+                 "+a"(arr[16 * k + 12]), "+a"(arr[16 * k + 13]), "+a"(arr[16 * k + 14]), "+a"(arr[16 * k + 15]))
+
+// I0 = (4096 - hop) / 256: the first kept 256-sample row group of a block.  A template parameter so that the 16 - I0
+// LDS reads and 16-byte stores per block are straight-line code (a test per store would serialise read -> store).
+template <int I0>
 __global__ __launch_bounds__(kOsWaveThreads) void fir_os_wave_kernel(
     const float *__restrict__ x, float *__restrict__ y, size_t n, const c32 *__restrict__ hspec, int ntaps,
-    unsigned blocks_per_channel, size_t total_blocks, size_t tiles, size_t chunk, const float *__restrict__ hist,
-    int zero_head, int hop) {
+    unsigned blocks_per_channel, size_t total_blocks, size_t tiles, size_t chunk) {
     constexpr int T = 64, P = kWavePoints;
+    constexpr int hop = kWaveN - 256 * I0;
+    typedef float f4 __attribute__((ext_vector_type(4)));
     extern __shared__ __attribute__((aligned(16))) unsigned char os_wave_lds[];
     c32 *hs = reinterpret_cast<c32 *>(os_wave_lds);
     const int lane = static_cast<int>(threadIdx.x) & 63;
@@ -508,63 +540,84 @@ __global__ __launch_bounds__(kOsWaveThreads) void fir_os_wave_kernel(
     }
     __syncthreads();  // the only workgroup barrier: from here on every wave runs on its own
 
-    const long long order = ntaps - 1;
-    const long long L = hop;                  // see fir_overlap_save_kernel: a multiple of 64 where possible
-    const long long keep0 = kWaveN - L;       // first kept output of a block (block 0: order)
-    const long long hoff = hist ? order : 0;  // streaming form: blocks run over history ++ x
-    const long long nn = static_cast<long long>(n) + hoff;
+    const long long L = hop;   // see fir_overlap_save_kernel; here a multiple of 256
+    constexpr int i0 = I0;     // 16 - i0 16-byte stores per block
+    const long long nn = static_cast<long long>(n);
     // each XCD streams one contiguous range of block pairs; its waves stride through it
     const size_t xcd = blockIdx.x & 7u;
     const size_t waves_per_xcd = static_cast<size_t>(gridDim.x >> 3) * kOsWaveWaves;
     const c32 *hlo = hs + lane;                  // H[lane + 64 m],         m < 32
     const c32 *hhi = hs + (kWaveN / 2 - lane);   // H[4096 - (lane + 64 m)], m >= 32:  hhi[-64 (m - 32)]
-    for (size_t t = static_cast<size_t>(blockIdx.x >> 3) * kOsWaveWaves + wave; t < chunk; t += waves_per_xcd) {
+
+    // Where a block pair lives (wave-uniform): element offsets of the two block starts in x / y.  `plain`: both blocks
+    // exist, lie wholly inside their channels and are not block 0 of a channel -- the only pairs this kernel transforms.
+    // The others (the pairs holding a channel's first or last block: zero head, outputs from `order` on, ragged end) are
+    // left to fir_overlap_save_kernel, launched over exactly those pairs (OsExtra::edge_pairs), which keeps every rare
+    // path out of this loop.
+    struct Pair {
+        size_t oa, ob;
+        bool valid, plain;
+    };
+    // (channel, block) of block q = 2 * tile, stepped along with t instead of divided out for every pair
+    const size_t t0 = static_cast<size_t>(blockIdx.x >> 3) * kOsWaveWaves + wave;
+    const size_t q0 = 2 * (xcd * chunk + t0), dq = 2 * waves_per_xcd;
+    size_t ch_q = q0 / blocks_per_channel;
+    unsigned blk_q = static_cast<unsigned>(q0 % blocks_per_channel);
+    const size_t dch = dq / blocks_per_channel;
+    const unsigned dblk = static_cast<unsigned>(dq % blocks_per_channel);
+    auto locate = [&](size_t t) {  // must be called with t = t0, t0 + waves_per_xcd, ... in turn
+        Pair p{};
         const size_t tile = xcd * chunk + t;
-        if (tile >= tiles) break;
+        p.valid = t < chunk && tile < tiles;
+        if (!p.valid) return p;
         // the two real blocks riding one complex transform are consecutive entries of the flattened (channel, block)
         // list: with an odd block count per channel a pair straddles two channels
-        const size_t qa = 2 * tile, qb = qa + 1;
-        const bool has_b = qb < total_blocks;
-        const size_t ch_a = qa / blocks_per_channel, ch_b = has_b ? qb / blocks_per_channel : ch_a;
-        const unsigned blk_a = static_cast<unsigned>(qa % blocks_per_channel), blk_b = static_cast<unsigned>(qb % blocks_per_channel);
-        const float *xa = x + ch_a * n - hoff;  // xa[v] valid for v >= hoff
-        const float *xb = x + ch_b * n - hoff;
-        float *ya = y + ch_a * n - hoff;
-        float *yb = y + ch_b * n - hoff;
-        const float *ha = hist ? hist + ch_a * order : nullptr;
-        const float *hb = hist ? hist + ch_b * order : nullptr;
-        const long long in_a = static_cast<long long>(blk_a) * L;
-        const long long in_b = has_b ? static_cast<long long>(blk_b) * L : nn;  // a missing block: nothing loaded, nothing stored
-        const bool interior = in_a >= hoff && in_a + kWaveN <= nn && in_b >= hoff && in_b + kWaveN <= nn;
+        const size_t ch_a = ch_q;
+        const unsigned blk_a = blk_q;
+        const bool has_b = 2 * tile + 1 < total_blocks;
+        const bool wrap = blk_a + 1 == blocks_per_channel;
+        const size_t ch_b = wrap ? ch_a + 1 : ch_a;
+        const unsigned blk_b = wrap ? 0u : blk_a + 1;
+        ch_q += dch;
+        blk_q += dblk;
+        if (blk_q >= blocks_per_channel) blk_q -= blocks_per_channel, ++ch_q;
+        const long long in_a = static_cast<long long>(blk_a) * L, in_b = static_cast<long long>(blk_b) * L;
+        p.oa = ch_a * n + static_cast<size_t>(in_a);
+        p.ob = ch_b * n + static_cast<size_t>(in_b);
+        p.plain = has_b && blk_a != 0 && blk_b != 0 && in_a + kWaveN <= nn && in_b + kWaveN <= nn;
+        return p;
+    };
 
+    float na[P], nb[P];  // the prefetched samples (AGPRs)
+#pragma unroll
+    for (int m = 0; m < P; ++m) na[m] = nb[m] = 0.0f;
+    auto prefetch = [&](const Pair &p) {
+        const float *a0 = x + p.oa + lane, *a1 = a0 + 1024, *a2 = a0 + 2048, *a3 = a0 + 3072;
+        const float *b0 = x + p.ob + lane, *b1 = b0 + 1024, *b2 = b0 + 2048, *b3 = b0 + 3072;
+        OSW_ROW16(na, 0, a0); OSW_ROW16(na, 1, a1); OSW_ROW16(na, 2, a2); OSW_ROW16(na, 3, a3);
+        OSW_ROW16(nb, 0, b0); OSW_ROW16(nb, 1, b1); OSW_ROW16(nb, 2, b2); OSW_ROW16(nb, 3, b3);
+    };
+
+    size_t t = t0;
+    Pair nxt = locate(t);
+    while (nxt.valid && !nxt.plain) nxt = locate(t += waves_per_xcd);
+    if (nxt.valid) prefetch(nxt);
+    bool stores_behind = false;  // exactly 2 * (16 - I0) stores were issued after the pending prefetch (else: wait for everything)
+    while (nxt.valid) {
+        float *const ya = y + nxt.oa + 4 * lane, *const yb = y + nxt.ob + 4 * lane;
+        // wait for the prefetch only: the youngest 2 * (16 - I0) operations are the previous pair's stores
+        if (stores_behind) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (16 - I0)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        OSW_TIE16(na, 0); OSW_TIE16(na, 1); OSW_TIE16(na, 2); OSW_TIE16(na, 3);
+        OSW_TIE16(nb, 0); OSW_TIE16(nb, 1); OSW_TIE16(nb, 2); OSW_TIE16(nb, 3);
         c32 r[P];
-        if (interior) {
-            const float *pa = xa + in_a + lane, *pb = xb + in_b + lane;
 #pragma unroll
-            for (int m = 0; m < P; ++m)
-                r[m] = mk(__builtin_nontemporal_load(pa + T * m), __builtin_nontemporal_load(pb + T * m));
-        } else {
-            // ragged pair (a channel's last blocks) or the first pair of a streamed chunk, which reaches into the carried
-            // history: rare, so the bounds handling runs as rolled loops that park the samples in the wave's LDS image
-            // (a lane reads back only what it wrote itself) instead of 128 unrolled guarded loads
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                const float *xs = half ? xb : xa, *hp = half ? hb : ha;
-                const long long in0 = (half ? in_b : in_a) + lane;
-#pragma unroll 1
-                for (int m = 0; m < P; ++m) {
-                    const long long i = in0 + T * m;
-                    float v = 0.0f;
-                    if (i < nn) v = i >= hoff ? xs[i] : hp[i];
-                    img[m * kWaveRow + lane] = v;
-                }
-#pragma unroll
-                for (int m = 0; m < P; ++m) {
-                    if (half) r[m].y = img[m * kWaveRow + lane];
-                    else r[m].x = img[m * kWaveRow + lane];
-                }
-            }
-        }
+        for (int m = 0; m < P; ++m) r[m] = mk(na[m], nb[m]);
+        asm volatile("" ::: "memory");  // the prefetch below overwrites na/nb: keep it behind the copies above
+        do nxt = locate(t += waves_per_xcd);
+        while (nxt.valid && !nxt.plain);
+        if (nxt.valid) prefetch(nxt);
+
         fft4096_wave<+1>(r, img, lane);
 #pragma unroll
         for (int m = 0; m < P; ++m) {  // bin k = lane + 64 m
@@ -573,44 +626,29 @@ __global__ __launch_bounds__(kOsWaveThreads) void fir_os_wave_kernel(
         }
         fft4096_wave<-1>(r, img, lane);
 
-        if (hoff == 0) {  // filter.h:126,133: the first `order` outputs of a channel stay zero
-            if (blk_a == 0)
-                for (long long j = lane; j < order && j < nn; j += T) ya[j] = 0.0f;
-            if (has_b && blk_b == 0)
-                for (long long j = lane; j < order && j < nn; j += T) yb[j] = 0.0f;
-        }
-        if (interior && blk_a != 0 && blk_b != 0) {  // every kept output is in range and past the zero head
-            float *pa = ya + in_a + lane, *pb = yb + in_b + lane;
-            // rows below m0 lie wholly in the dropped part of the block, row m0 partly (not at all with an aligned hop):
-            // wave-uniform tests, so that no per-row lane mask is kept in scalar registers across the loop
-            int m0 = static_cast<int>(keep0) / T, l0 = static_cast<int>(keep0) % T;
-            asm volatile("" : "+s"(m0), "+s"(l0));  // not loop invariants: 64 hoisted lane masks would spill scalar registers
+        // Outputs k in [256 * I0, 4096) of both blocks are kept.  They leave as 16-byte stores: each plane is re-laid out
+        // through the LDS image (rows of 64 floats, linear), a lane then owns 4 consecutive outputs and a wave
+        // instruction writes 1 KB.
 #pragma unroll
-            for (int m = 0; m < P; ++m) {
-                if (m < m0) continue;
-                if (m == m0 && lane < l0) continue;
-                __builtin_nontemporal_store(r[m].x, pa + T * m);
-                __builtin_nontemporal_store(r[m].y, pb + T * m);
-            }
-            continue;
-        }
+        for (int half = 0; half < 2; ++half) {
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {  // rare: rolled, through the LDS image like the loads
+            for (int m = 4 * i0; m < P; ++m) img[m * 64 + lane] = half ? r[m].y : r[m].x;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            float *dst = half ? yb : ya;
+            f4 v[16 - i0];
 #pragma unroll
-            for (int m = 0; m < P; ++m) img[m * kWaveRow + lane] = half ? r[m].y : r[m].x;
-            float *ys = half ? yb : ya;
-            const long long in0 = half ? in_b : in_a;
-            const long long first = (half ? blk_b : blk_a) == 0 ? order : keep0;
-#pragma unroll 1
-            for (int m = 0; m < P; ++m) {
-                const long long k = lane + T * m;
-                if (k < first) continue;  // wrapped (circular) part of the block, or the previous block's outputs
-                const long long j = in0 + k;
-                // streaming: outputs before the stream's first full window stay zero like the one-shot head
-                if (j < nn) ys[j] = j - hoff < zero_head ? 0.0f : img[m * kWaveRow + lane];
-            }
+            for (int i = i0; i < 16; ++i) v[i - i0] = *reinterpret_cast<const f4 *>(img + 256 * i + 4 * lane);
+#pragma unroll
+            for (int i = i0; i < 16; ++i) __builtin_nontemporal_store(v[i - i0], reinterpret_cast<f4 *>(dst + 256 * i));
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
+        stores_behind = true;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no prefetch is pending here; belt and braces
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -869,7 +907,10 @@ int launch_os(const float *x, float *y, size_t channels, size_t n, const c32 *d_
     // hop between blocks: N - order at most; one-shot calls round it down to a multiple of 64 samples when that costs
     // at most 1/32 of it (block starts, and with them every wave's loads and stores, then sit on 256-byte boundaries)
     long long L = kOsN - order;
-    if (!hist && !ex.zero_hist && (L & 63) != 0 && (L & ~63ll) >= 64 && (L & 63) * 32 <= L) L &= ~63ll;
+    if (!hist && !ex.zero_hist) {
+        if ((L & 255) * 32 <= L && (L & ~255ll) >= 256) L &= ~255ll;       // 1 KB: what the one-wave kernel's 16-byte stores want
+        else if ((L & 63) * 32 <= L && (L & ~63ll) >= 64) L &= ~63ll;
+    }
     const long long nv = static_cast<long long>(n) + ((hist || ex.zero_hist) ? order : 0);  // length of the (virtual) signal
     const long long valid = nv > order ? nv - order : 0;
     // block 0 delivers N - order outputs, every later block L
@@ -878,8 +919,10 @@ int launch_os(const float *x, float *y, size_t channels, size_t n, const c32 *d_
     const unsigned bpc = static_cast<unsigned>(nblocks);
     const size_t total_blocks = channels * static_cast<size_t>(nblocks);
     const size_t tiles = (total_blocks + 1) / 2;  // two real blocks per complex transform, across channels if need be
-    if (log2n == 12 && tiles >= os_wave_min_tiles() && !ex.accumulate && !ex.zero_hist && ex.stride == n && ex.yoff == 0) {
-        // long signals: one wave per block pair, persistent workgroups (one per CU: its LDS fills the CU)
+    if (log2n == 12 && tiles >= os_wave_min_tiles() && !hist && !ex.accumulate && !ex.zero_hist && ex.stride == n && ex.yoff == 0 &&
+        (L & 255) == 0 && L >= 2048 && L <= 3840 && (n & 3) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0 &&
+        (reinterpret_cast<uintptr_t>(x) & 3) == 0) {
+        // long signals: one wave per block pair, persistent workgroups (one per CU: four waves, one per SIMD)
         static const int cus = [] {
             int dev = 0, v = 256;
             if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev);
@@ -888,13 +931,31 @@ int launch_os(const float *x, float *y, size_t channels, size_t n, const c32 *d_
         const size_t chunkw = (tiles + 7) / 8;
         size_t wgs = (static_cast<size_t>(cus) + 7) / 8 * 8;
         wgs = std::min(wgs, (chunkw + kOsWaveWaves - 1) / kOsWaveWaves * 8);
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(fir_os_wave_kernel),
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                           static_cast<int>(kOsWaveLdsBytes));
-        if (attr != hipSuccess) return fail(DSP_GPU_EHIP, "fir_os_wave_kernel: LDS attribute: %s", hipGetErrorString(attr));
-        hipLaunchKernelGGL(fir_os_wave_kernel, dim3(static_cast<unsigned>(wgs)), dim3(kOsWaveThreads), kOsWaveLdsBytes, s, x, y, n,
-                           d_hspec, ntaps, bpc, total_blocks, tiles, chunkw, hist, zero_head, hop);
-        return check_launch("fir_os_wave_kernel");
+        const dim3 wgrid(static_cast<unsigned>(wgs));
+#define DSPGPU_OSW_CASE(I0)                                                                                              \
+    case I0: {                                                                                                          \
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(fir_os_wave_kernel<I0>),      \
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize,                  \
+                                                           static_cast<int>(kOsWaveLdsBytes));                          \
+        if (attr != hipSuccess) return fail(DSP_GPU_EHIP, "fir_os_wave_kernel: LDS attribute: %s", hipGetErrorString(attr)); \
+        hipLaunchKernelGGL(fir_os_wave_kernel<I0>, wgrid, dim3(kOsWaveThreads), kOsWaveLdsBytes, s, x, y, n, d_hspec, ntaps, \
+                           bpc, total_blocks, tiles, chunkw);                                                           \
+    } break
+        switch (static_cast<int>((kOsN - L) / 256)) {
+            DSPGPU_OSW_CASE(1); DSPGPU_OSW_CASE(2); DSPGPU_OSW_CASE(3); DSPGPU_OSW_CASE(4);
+            DSPGPU_OSW_CASE(5); DSPGPU_OSW_CASE(6); DSPGPU_OSW_CASE(7); DSPGPU_OSW_CASE(8);
+        default: return fail(DSP_GPU_EINVAL, "fir_os_wave_kernel: hop %lld", L);
+        }
+#undef DSPGPU_OSW_CASE
+        if (int rc = check_launch("fir_os_wave_kernel")) return rc;
+        // the pairs it left out -- those holding a channel's first or last block -- on the workgroup kernel: two per channel
+        OsExtra edge = ex;
+        edge.edge_pairs = 1;
+        if (2 * channels > 0x7fffffffull) return fail(DSP_GPU_EUNSUPPORTED, "overlap-save FIR: grid too large");
+        hipLaunchKernelGGL(fir_overlap_save_kernel<12>, dim3(static_cast<unsigned>(2 * channels)), dim3(256),
+                           (4096 + 4096 / 16) * sizeof(c32), s, x, y, n, d_hspec, ntaps, bpc, total_blocks, tiles, tiles,
+                           (tiles + 7) / 8, hist, zero_head, edge, hop);
+        return check_launch("fir_overlap_save_kernel (edge pairs)");
     }
     const size_t per_wg = kOsN < 4096 ? static_cast<size_t>(4096 / kOsN) : 1;  // transforms per workgroup
     const size_t wg_tiles = (tiles + per_wg - 1) / per_wg;
@@ -927,7 +988,7 @@ int launch_os(const float *x, float *y, size_t channels, size_t n, const c32 *d_
 int launch_fir_overlap_save(const float *x, float *y, size_t channels, size_t n, const float2 *d_hspec_f2, int ntaps,
                             const float *hist, int zero_head, int log2n, hipStream_t s) {
     return launch_os(x, y, channels, n, reinterpret_cast<const c32 *>(d_hspec_f2), ntaps, hist, zero_head,
-                     OsExtra{n, 0, 0, 0}, log2n, s);
+                     OsExtra{n, 0, 0, 0, 0}, log2n, s);
 }
 
 // One segment of a partitioned long filter (taps [seg0, seg0 + seg_len) of it): y[.][seg0 + j] (+)= sum_i h_seg[i] x[.][j - i]
@@ -936,7 +997,7 @@ int launch_fir_os_segment(const float *x, float *y, size_t channels, size_t n, c
                           size_t seg0, int accumulate, int log2n, hipStream_t s) {
     if (seg0 >= n) return DSP_GPU_OK;
     return launch_os(x, y, channels, n - seg0, reinterpret_cast<const c32 *>(d_hspec_f2), seg_len, nullptr, 0,
-                     OsExtra{n, seg0, accumulate, 1}, log2n, s);
+                     OsExtra{n, seg0, accumulate, 1, 0}, log2n, s);
 }
 
 int launch_moving_average(const float *x, float *y, size_t channels, size_t n, int npoints, hipStream_t s) {
