@@ -50,6 +50,13 @@ DSP_DEV c32 mul_w64(c32 a, int q) {
 template <int SIGN>
 struct Dft<64, SIGN> {
     static DSP_DEV void run(c32 (&v)[64]) {
+        run(v, [](int) {});
+    }
+    // `hook(0..7)` runs after each of the four 16-point sub-transforms and after every fourth 4-point one: callers hang
+    // other work there (the overlap-save
+    // kernel issues its prefetch loads a few at a time, so that a full memory queue never holds up the arithmetic long)
+    template <typename Hook>
+    static DSP_DEV void run(c32 (&v)[64], Hook hook) {
 #pragma unroll
         for (int n2 = 0; n2 < 4; ++n2) {  // A[k1][n2] = sum_n1 v[4 n1 + n2] W16^{n1 k1}, left at v[4 k1 + n2]
             c32 t[16];
@@ -58,6 +65,7 @@ struct Dft<64, SIGN> {
             Dft<16, SIGN>::run(t);
 #pragma unroll
             for (int i = 0; i < 16; ++i) v[4 * i + n2] = t[i];
+            hook(n2);
         }
 #pragma unroll
         for (int k1 = 1; k1 < 16; ++k1) {
@@ -65,7 +73,10 @@ struct Dft<64, SIGN> {
             for (int n2 = 1; n2 < 4; ++n2) v[4 * k1 + n2] = mul_w64<SIGN>(v[4 * k1 + n2], n2 * k1);
         }
 #pragma unroll
-        for (int k1 = 0; k1 < 16; ++k1) dft4<SIGN>(v[4 * k1], v[4 * k1 + 1], v[4 * k1 + 2], v[4 * k1 + 3]);
+        for (int k1 = 0; k1 < 16; ++k1) {
+            dft4<SIGN>(v[4 * k1], v[4 * k1 + 1], v[4 * k1 + 2], v[4 * k1 + 3]);
+            if ((k1 & 3) == 3) hook(4 + (k1 >> 2));
+        }
         c32 o[64];  // X[k1 + 16 k2] sits at v[4 k1 + k2]: a renaming, no instruction
 #pragma unroll
         for (int k1 = 0; k1 < 16; ++k1) {
@@ -77,10 +88,31 @@ struct Dft<64, SIGN> {
     }
 };
 
-// Lane l holds r[j] = M[j][l]; afterwards r[j] = M[l][j].  `img` is this wave's private plane of kWaveLdsFloats
-// floats.  A wave's LDS instructions execute in order, so the loads see the stores of every lane without any
-// hardware barrier; the wavefront-scope fences only keep the compiler from reordering across them.
+// Lane l holds r[j] = M[j][l]; afterwards r[j] = M[l][j].  A wave's LDS instructions execute in order, so the loads
+// see the stores of every lane without any hardware barrier; the wavefront-scope fences only keep the compiler from
+// reordering memory accesses across them.
+// Two forms.  WIDE: `img` is a wave-private image of 64 x 65 complex values (33,280 B) and the points cross whole, one
+// store and one load phase of 8-byte accesses (row stride 65 complex = 130 dwords: lane l reads dword bank
+// (2l + 2j) mod 64, distinct over each half wave).  Otherwise `img` is one fp32 plane (16,640 B) that the real and the
+// imaginary parts cross one after the other -- half the LDS, twice the dependent phases.
+constexpr int kWaveLdsWideBytes = 64 * kWaveRow * 8;
+
+template <bool WIDE>
 DSP_DEV void wave_transpose(c32 (&r)[kWavePoints], float *img, int lane) {
+    if constexpr (WIDE) {
+        c32 *im2 = reinterpret_cast<c32 *>(img);
+        c32 *wr = im2 + lane;
+        const c32 *rd = im2 + lane * kWaveRow;
+#pragma unroll
+        for (int j = 0; j < kWavePoints; ++j) wr[j * kWaveRow] = r[j];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int j = 0; j < kWavePoints; ++j) r[j] = rd[j];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        return;
+    }
     float *wr = img + lane;             // row j, column lane:  wr[j * kWaveRow]
     float *rd = img + lane * kWaveRow;  // row lane, column j:  rd[j]
 #pragma unroll
@@ -109,9 +141,18 @@ DSP_DEV void wave_transpose(c32 (&r)[kWavePoints], float *img, int lane) {
 //   n = 64 n1 + n2, k = k1 + 64 k2:
 //   X[k1 + 64 k2] = sum_n2 W64^{n2 k2} ( W4096^{n2 k1} sum_n1 x[64 n1 + n2] W64^{n1 k1} )
 // pass 1 over n1 in the registers of lane n2; twiddle W4096^{lane * k1}; transpose; pass 2 over n2 in lane k1.
-template <int SIGN>
+template <int SIGN, bool WIDE, typename Hook>
+DSP_DEV void fft4096_wave(c32 (&r)[kWavePoints], float *img, int lane, Hook hook);
+
+template <int SIGN, bool WIDE = false>
 DSP_DEV void fft4096_wave(c32 (&r)[kWavePoints], float *img, int lane) {
-    Dft<64, SIGN>::run(r);
+    fft4096_wave<SIGN, WIDE>(r, img, lane, [](int) {});
+}
+
+// `hook(0..15)` runs at sixteen points spread over the transform (see Dft<64>::run)
+template <int SIGN, bool WIDE, typename Hook>
+DSP_DEV void fft4096_wave(c32 (&r)[kWavePoints], float *img, int lane, Hook hook) {
+    Dft<64, SIGN>::run(r, [&](int i) { hook(i); });
     {
         // W^{lane * k1}, k1 = 8a + b:  (W^{8 lane})^a * (W^{lane})^b -- one sincospif, two short product trees
         const c32 w = unit_root<SIGN>(static_cast<unsigned>(lane), 12);
@@ -132,8 +173,8 @@ DSP_DEV void fft4096_wave(c32 (&r)[kWavePoints], float *img, int lane) {
             }
         }
     }
-    wave_transpose(r, img, lane);
-    Dft<64, SIGN>::run(r);
+    wave_transpose<WIDE>(r, img, lane);
+    Dft<64, SIGN>::run(r, [&](int i) { hook(8 + i); });
 }
 
 }  // namespace dspgpu

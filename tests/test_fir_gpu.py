@@ -342,3 +342,28 @@ def test_direct_short_channels(ops, dev, orc, n, ntaps, channels):
         hist = torch.zeros(channels, ntaps - 1, device=dev)
         outs = [ops.convolve_stream(xd[:, p:p + 256].contiguous(), h, hist, p, mode="direct") for p in range(0, n, 256)]
         assert rel_l2(torch.cat(outs, dim=1).cpu().numpy(), want) <= DIRECT_TOL or not want.any()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("channels,n,ntaps", [(6, 40000, 511), (3, 65536, 255), (2, 100000, 1025), (5, 30720, 64),
+                                              (1, 3584 * 9 + 4096, 511), (4, 20480, 2049), (7, 12288, 300), (2, 50000, 1800)])
+def test_overlap_save_wave_kernel(ops, dev, orc, channels, n, ntaps, monkeypatch):
+    """The one-wave-per-block-pair kernel (long signals by default) forced onto small inputs: against the oracle and
+    against the workgroup kernel, incl. pairs that straddle channels, first / last blocks (edge pairs) and hops
+    that do not round to a multiple of 256 (those calls fall back to the workgroup kernel by themselves)."""
+    import torch
+    rng = np.random.default_rng(ntaps + n)
+    h = rng.standard_normal(ntaps) / np.sqrt(ntaps)
+    x = rng.standard_normal((channels, n)).astype(np.float32)
+    xd = torch.from_numpy(x).to(dev)
+    want = orc.fir(x.astype(np.float64), h)
+    monkeypatch.setenv("DSP_GPU_OS_WAVE_MIN_TILES", "1")
+    guard = torch.full((channels + 2, n), 9.0, device=dev)
+    ops.convolve(xd, h, "overlap_save", out=guard[1:-1])
+    g = guard.cpu().numpy()
+    assert (g[0] == 9).all() and (g[-1] == 9).all()
+    assert rel_l2(g[1:-1], want) <= OS_TOL
+    assert (g[1:-1, :ntaps - 1] == 0).all()
+    monkeypatch.setenv("DSP_GPU_OS_WAVE_MIN_TILES", "999999999")
+    other = ops.convolve(xd, h, "overlap_save").cpu().numpy()
+    assert rel_l2(g[1:-1], other) <= 5e-6
