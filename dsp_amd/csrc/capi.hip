@@ -4,9 +4,11 @@
 // per-device workspaces and the cache of uploaded tap sets, and forwards to the kernel
 // launchers.  Nothing here computes samples on the CPU: if HIP is unusable the calls
 // fail with DSP_GPU_EHIP.
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <mutex>
+#include <unordered_map>
 #include <vector>
 
 #include "common.h"
@@ -32,15 +34,36 @@ constexpr int kSegmentLog2N = 14;             // partitioned long filters use 16
 constexpr int kSegmentTaps = 8192;            // ... of 8192 taps per overlap-save pass (hop 8193)
 constexpr int kMaxPartitionedTaps = 1 << 18;  // 32 passes
 
-struct TapEntry {  // uploaded tap set (+ lazily built overlap-save spectrum)
-    std::vector<float> taps;
+// One uploaded tap set (+ lazily built overlap-save spectra).  The cache is a fixed pool of slots with LRU
+// replacement: a new tap set TAKES OVER the least recently used idle slot together with its device buffers (nothing is
+// freed, so nothing synchronises the device), after waiting on the host for that slot's own last use only.
+// A slot is handed out as a lease: pinned (never a victim) until the call that holds it has launched its kernels and
+// recorded `last_use` on its stream.
+struct TapSlot {
+    std::vector<float> taps;   // host copy: the key, and the source of the (asynchronous) upload
+    unsigned long long hash = 0;
     float *d_taps = nullptr;
-    float2 *d_spectrum[15] = {};  // [log2n]: spectrum of the taps zero padded to 2^log2n points (8 ... 12 and 14 in use)
+    size_t cap_taps = 0;       // floats d_taps holds
+    float2 *d_spectrum[15] = {};   // [log2n]: buffers, kept across take-overs
+    bool spectrum_valid[15] = {};  // spectrum of the CURRENT taps zero padded to 2^log2n points (8 ... 12 and 14 in use)
+    hipEvent_t ready = nullptr;     // taps + spectra built (recorded on the building stream)
+    hipEvent_t last_use = nullptr;  // recorded by every call after its kernels
+    bool used = false;
+    int pins = 0;
+    unsigned long long stamp = 0;  // LRU clock
+};
+
+struct TapLease {  // what a call gets: pointers by value, valid until release_taps()
+    int dev = -1;
+    int slot = -1;
+    const float *d_taps = nullptr;
+    const float2 *d_spectrum = nullptr;
 };
 
 struct DeviceState {
     Buffer ws[WS_SLOTS];
-    std::vector<TapEntry> taps;
+    std::vector<TapSlot> taps;  // sized once (kTapCacheEntries): slots never move
+    unsigned long long clock = 0;
 };
 
 std::mutex g_mutex;
@@ -52,58 +75,94 @@ int current_device(int *dev) {
     return DSP_GPU_OK;
 }
 
-// Find or upload a tap set on the current device.  Sets are tiny (<= 16 KiB) and few.
-int cached_taps(const float *taps, int ntaps, int spectrum_log2n, hipStream_t s, TapEntry **out) {  // 0: no spectrum
+unsigned long long tap_hash(const float *taps, int ntaps) {  // FNV-1a over the bytes
+    unsigned long long h = 1469598103934665603ull ^ static_cast<unsigned long long>(ntaps);
+    const unsigned char *p = reinterpret_cast<const unsigned char *>(taps);
+    for (size_t i = 0; i < sizeof(float) * static_cast<size_t>(ntaps); ++i) h = (h ^ p[i]) * 1099511628211ull;
+    return h;
+}
+
+// Find or upload a tap set on the current device; spectrum_log2n == 0: no spectrum wanted.  On success the slot is
+// pinned: the caller launches its kernels on `s` and then calls release_taps(lease, s).
+int acquire_taps(const float *taps, int ntaps, int spectrum_log2n, hipStream_t s, TapLease *out) {
+    if (spectrum_log2n < 0 || spectrum_log2n > 14) return fail(DSP_GPU_EINVAL, "tap spectrum of 2^%d points", spectrum_log2n);
     int dev = 0;
     if (int rc = current_device(&dev)) return rc;
+    const unsigned long long h = tap_hash(taps, ntaps);
     std::lock_guard<std::mutex> lock(g_mutex);
     DeviceState &st = g_dev[dev];
-    TapEntry *hit = nullptr;
-    for (TapEntry &e : st.taps)
-        if (static_cast<int>(e.taps.size()) == ntaps && std::memcmp(e.taps.data(), taps, sizeof(float) * ntaps) == 0) {
+    if (st.taps.empty()) st.taps.resize(kTapCacheEntries);
+    TapSlot *hit = nullptr, *victim = nullptr;
+    for (TapSlot &e : st.taps) {
+        if (e.used && e.hash == h && static_cast<int>(e.taps.size()) == ntaps &&
+            std::memcmp(e.taps.data(), taps, sizeof(float) * ntaps) == 0) {
             hit = &e;
             break;
         }
+        if (e.pins == 0 && (!victim || (!e.used && victim->used) || (e.used == victim->used && e.stamp < victim->stamp))) victim = &e;
+    }
+    bool fresh = false;
     if (!hit) {
-        if (st.taps.size() >= kTapCacheEntries) {  // bounded cache: drop everything when full
-            DSPGPU_HIP(hipDeviceSynchronize());
-            for (TapEntry &e : st.taps) {
-                if (e.d_taps) (void)hipFree(e.d_taps);
-                for (float2 *sp : e.d_spectrum)
-                    if (sp) (void)hipFree(sp);
-            }
-            st.taps.clear();
+        if (!victim) return fail(DSP_GPU_ENOMEM, "tap cache: all %zu slots are in use by running calls", kTapCacheEntries);
+        hit = victim;
+        if (!hit->ready) {
+            DSPGPU_HIP(hipEventCreateWithFlags(&hit->ready, hipEventDisableTiming));
+            DSPGPU_HIP(hipEventCreateWithFlags(&hit->last_use, hipEventDisableTiming));
+        } else if (hit->used) {
+            DSPGPU_HIP(hipEventSynchronize(hit->last_use));  // this slot's own last kernels only; an LRU victim is long idle
         }
-        TapEntry e;
-        e.taps.assign(taps, taps + ntaps);
-        if (hipMalloc(&e.d_taps, sizeof(float) * ntaps) != hipSuccess)
-            return fail(DSP_GPU_ENOMEM, "hipMalloc of %d taps failed", ntaps);
-        // synchronous copy from pageable host memory: done once per tap set
-        hipError_t ce = hipMemcpy(e.d_taps, taps, sizeof(float) * ntaps, hipMemcpyHostToDevice);
-        if (ce != hipSuccess) {
-            (void)hipFree(e.d_taps);
-            return fail(DSP_GPU_EHIP, "tap upload failed: %s", hipGetErrorString(ce));
+        hit->used = false;
+        if (hit->cap_taps < static_cast<size_t>(ntaps)) {  // grow (rare): frees only a buffer nothing uses any more
+            if (hit->d_taps) (void)hipFree(hit->d_taps);
+            hit->d_taps = nullptr;
+            hit->cap_taps = 0;
+            const size_t cap = std::max<size_t>(static_cast<size_t>(ntaps), 1024);
+            if (hipMalloc(&hit->d_taps, sizeof(float) * cap) != hipSuccess)
+                return fail(DSP_GPU_ENOMEM, "hipMalloc of %d taps failed", ntaps);
+            hit->cap_taps = cap;
         }
-        st.taps.reserve(kTapCacheEntries);
-        st.taps.push_back(std::move(e));
-        hit = &st.taps.back();
+        hit->taps.assign(taps, taps + ntaps);
+        hit->hash = h;
+        for (bool &v : hit->spectrum_valid) v = false;
+        // asynchronous upload from the slot's own host copy (stable until the slot is taken over again)
+        DSPGPU_HIP(hipMemcpyAsync(hit->d_taps, hit->taps.data(), sizeof(float) * ntaps, hipMemcpyHostToDevice, s));
+        hit->used = true;
+        fresh = true;
     }
-    if (spectrum_log2n < 0 || spectrum_log2n > 14) return fail(DSP_GPU_EINVAL, "tap spectrum of 2^%d points", spectrum_log2n);
-    if (spectrum_log2n && !hit->d_spectrum[spectrum_log2n]) {
-        float2 *sp = nullptr;
-        if (hipMalloc(&sp, sizeof(float2) << spectrum_log2n) != hipSuccess)
+    if (spectrum_log2n && !hit->spectrum_valid[spectrum_log2n]) {
+        if (!fresh) DSPGPU_HIP(hipStreamWaitEvent(s, hit->ready, 0));  // the taps may have been uploaded on another stream
+        if (!hit->d_spectrum[spectrum_log2n] &&
+            hipMalloc(&hit->d_spectrum[spectrum_log2n], sizeof(float2) << spectrum_log2n) != hipSuccess)
             return fail(DSP_GPU_ENOMEM, "hipMalloc of the tap spectrum failed");
-        if (int rc = launch_fir_spectrum(hit->d_taps, ntaps, sp, spectrum_log2n, s)) {
-            (void)hipFree(sp);
-            return rc;
-        }
-        // the spectrum is built on `s`; later users on other streams must see it complete
-        DSPGPU_HIP(hipStreamSynchronize(s));
-        hit->d_spectrum[spectrum_log2n] = sp;
+        if (int rc = launch_fir_spectrum(hit->d_taps, ntaps, hit->d_spectrum[spectrum_log2n], spectrum_log2n, s)) return rc;
+        hit->spectrum_valid[spectrum_log2n] = true;
+        fresh = true;
     }
-    *out = hit;
+    if (fresh) DSPGPU_HIP(hipEventRecord(hit->ready, s));          // later users on other streams wait for this
+    else DSPGPU_HIP(hipStreamWaitEvent(s, hit->ready, 0));         // same stream: a no-op in effect
+    hit->stamp = ++st.clock;
+    ++hit->pins;
+    out->dev = dev;
+    out->slot = static_cast<int>(hit - st.taps.data());
+    out->d_taps = hit->d_taps;
+    out->d_spectrum = spectrum_log2n ? hit->d_spectrum[spectrum_log2n] : nullptr;
     return DSP_GPU_OK;
 }
+
+// The call has launched everything that reads the lease's buffers on `s`.
+void release_taps(const TapLease &lease, hipStream_t s) {
+    if (lease.slot < 0) return;
+    std::lock_guard<std::mutex> lock(g_mutex);
+    TapSlot &e = g_dev[lease.dev].taps[lease.slot];
+    (void)hipEventRecord(e.last_use, s);
+    --e.pins;
+}
+
+struct LeaseGuard {  // releases on every return path
+    TapLease lease;
+    hipStream_t s;
+    ~LeaseGuard() { release_taps(lease, s); }
+};
 
 // Block length of one overlap-save pass.  4096 points hold 2049 taps, 16384 points 8193.  A channel short enough to
 // fit ONE 4096-point block is cut into the 256- ... 4096-point blocks that cost the fewest butterflies
@@ -169,25 +228,47 @@ int workspace(WorkspaceSlot slot, size_t bytes, void **ptr) {
     return DSP_GPU_OK;
 }
 
+int allow_full_lds(const void *fn) {
+    static std::mutex m;
+    static std::unordered_map<const void *, unsigned long long> done;  // kernel -> devices it has been set on
+    int dev = 0;
+    if (int rc = current_device(&dev)) return rc;
+    const unsigned long long bit = 1ull << dev;
+    std::lock_guard<std::mutex> lock(m);
+    unsigned long long &mask = done[fn];
+    if (mask & bit) return DSP_GPU_OK;
+    DSPGPU_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    mask |= bit;
+    return DSP_GPU_OK;
+}
+
 void release_all_workspaces() {
-    std::lock_guard<std::mutex> lock(g_mutex);
     int saved = 0, count = 0;
     if (hipGetDevice(&saved) != hipSuccess || hipGetDeviceCount(&count) != hipSuccess) return;
     for (int d = 0; d < count && d < kMaxDevices; ++d) {
-        DeviceState &st = g_dev[d];
-        bool used = !st.taps.empty();
-        for (const Buffer &b : st.ws) used = used || b.ptr;
+        bool used = iir_tables_in_use(d);
+        {
+            std::lock_guard<std::mutex> lock(g_mutex);
+            DeviceState &st = g_dev[d];
+            used = used || !st.taps.empty();
+            for (const Buffer &b : st.ws) used = used || b.ptr;
+        }
         if (!used) continue;
         if (hipSetDevice(d) != hipSuccess) continue;
         (void)hipDeviceSynchronize();
+        release_iir_tables(d);
+        std::lock_guard<std::mutex> lock(g_mutex);
+        DeviceState &st = g_dev[d];
         for (Buffer &b : st.ws) {
             if (b.ptr) (void)hipFree(b.ptr);
             b = Buffer{};
         }
-        for (TapEntry &e : st.taps) {
+        for (TapSlot &e : st.taps) {
             if (e.d_taps) (void)hipFree(e.d_taps);
             for (float2 *sp : e.d_spectrum)
                 if (sp) (void)hipFree(sp);
+            if (e.ready) (void)hipEventDestroy(e.ready);
+            if (e.last_use) (void)hipEventDestroy(e.last_use);
         }
         st.taps.clear();
     }
@@ -322,9 +403,9 @@ static int convolve_impl(const char *who, const float *x, float *y, size_t chann
         }
         for (int seg0 = 0; seg0 < ntaps; seg0 += kSegmentTaps) {
             const int len = std::min(kSegmentTaps, ntaps - seg0);
-            TapEntry *seg = nullptr;
-            if (int rc = cached_taps(taps + seg0, len, kSegmentLog2N, s, &seg)) return rc;
-            if (int rc = launch_fir_os_segment(dx, dy, channels, n, seg->d_spectrum[kSegmentLog2N], len, static_cast<size_t>(seg0),
+            LeaseGuard seg{TapLease{}, s};
+            if (int rc = acquire_taps(taps + seg0, len, kSegmentLog2N, s, &seg.lease)) return rc;
+            if (int rc = launch_fir_os_segment(dx, dy, channels, n, seg.lease.d_spectrum, len, static_cast<size_t>(seg0),
                                                seg0 > 0, kSegmentLog2N, s))
                 return rc;
         }
@@ -333,8 +414,8 @@ static int convolve_impl(const char *who, const float *x, float *y, size_t chann
         if (head) DSPGPU_HIP(hipMemset2DAsync(dy, n * sizeof(float), 0, head * sizeof(float), channels, s));
         return mem == DSP_GPU_MEM_HOST ? stage_out(y, bytes, s, hs) : DSP_GPU_OK;
     }
-    TapEntry *te = nullptr;
-    if (int rc = cached_taps(taps, ntaps, mode == DSP_GPU_CONV_OVERLAP_SAVE ? os_log2n : 0, s, &te)) return rc;
+    LeaseGuard te{TapLease{}, s};
+    if (int rc = acquire_taps(taps, ntaps, mode == DSP_GPU_CONV_OVERLAP_SAVE ? os_log2n : 0, s, &te.lease)) return rc;
     const size_t hist_bytes = channels * static_cast<size_t>(ntaps - 1) * sizeof(float);
     const float *dx = x;
     float *dy = y;
@@ -357,9 +438,9 @@ static int convolve_impl(const char *who, const float *x, float *y, size_t chann
     const unsigned long long order = static_cast<unsigned long long>(ntaps - 1);
     const int zero_head = position >= order ? 0 : static_cast<int>(order - position);
     int rc = mode == DSP_GPU_CONV_OVERLAP_SAVE
-                 ? launch_fir_overlap_save(dx, dy, channels, n, te->d_spectrum[os_log2n], ntaps, old_hist, zero_head, os_log2n, s)
-             : mode == DSP_GPU_CONV_DIRECT_VALU ? launch_fir_direct_valu(dx, dy, channels, n, te->d_taps, ntaps, s)
-                                                : launch_fir_direct(dx, dy, channels, n, te->d_taps, ntaps, old_hist, zero_head, s);
+                 ? launch_fir_overlap_save(dx, dy, channels, n, te.lease.d_spectrum, ntaps, old_hist, zero_head, os_log2n, s)
+             : mode == DSP_GPU_CONV_DIRECT_VALU ? launch_fir_direct_valu(dx, dy, channels, n, te.lease.d_taps, ntaps, s)
+                                                : launch_fir_direct(dx, dy, channels, n, te.lease.d_taps, ntaps, old_hist, zero_head, s);
     if (rc) return rc;
     if (history && hist_bytes) {  // new history = last ntaps-1 samples of (old history ++ x), via a scratch copy
         void *p = nullptr;

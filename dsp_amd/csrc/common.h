@@ -60,7 +60,11 @@ enum WorkspaceSlot {
     WS_STAGE_IN = 0, WS_STAGE_OUT, WS_SCRATCH_A, WS_SCRATCH_B, WS_STATE, WS_STATE_SNAP, WS_IIR_TABLE, WS_FIR_HIST, WS_SLOTS
 };
 int workspace(WorkspaceSlot slot, size_t bytes, void **ptr);
+// Lets kernel `fn` use up to the CU's whole 160 KiB of dynamic LDS; issued once per kernel and device, not per launch.
+int allow_full_lds(const void *fn);
 void release_all_workspaces();
+bool iir_tables_in_use(int dev);
+void release_iir_tables(int dev);  // cached IIR scan tables of device `dev`, which must be current and idle (dsp_gpu_shutdown)
 
 // ---- kernel launchers (device pointers, asynchronous on `s`) --------------------------
 int launch_fft_batch(const float2 *in, float2 *out, int log2n, size_t batch, int direction, hipStream_t s);

@@ -523,8 +523,7 @@ int launch_big(const void *in, c32 *out, size_t batch, size_t n_in, size_t in_st
     auto kf = fft_big_kernel<LOG2N, +1, REAL_IN, SHIFTED>;
     auto ki = fft_big_kernel<LOG2N, -1, REAL_IN, SHIFTED>;
     auto kern = direction == DSP_GPU_FORWARD ? kf : ki;
-    DSPGPU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   static_cast<int>(lds_bytes)));
+    if (int rc = allow_full_lds(reinterpret_cast<const void *>(kern))) return rc;
     hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(8 * per_xcd)), dim3(N / kPoints), lds_bytes, s, in, out, batch, chunk,
                        n_in, in_stride);
     return check_launch("fft_big_kernel");
@@ -550,6 +549,23 @@ int launch_fft_columns(const float2 *in_f2, float2 *out_f2, int log2n, size_t co
     c32 *out = reinterpret_cast<c32 *>(out_f2);
     if (log2n < 4 || log2n > 16) return fail(DSP_GPU_EINVAL, "fft_columns: log2n %d outside [4,16]", log2n);
     if (in == out) return fail(DSP_GPU_EINVAL, "fft_columns: in-place is not supported");
+    {
+        // A column pass of length L moves 4096 / L adjacent columns per workgroup.  Narrower matrices (small transforms
+        // spread over many ranks: 2^10 points on one rank give 32 columns against a tile of 128) take the general route:
+        // transpose, transform the rows, transpose back.
+        const int la = log2n <= 8 ? log2n : (log2n + 1) / 2, lb = log2n <= 8 ? 0 : log2n - la;
+        const size_t na = static_cast<size_t>(1) << la, nb = static_cast<size_t>(1) << lb;
+        const bool fits = (nb * cols) % (kTile >> la) == 0 && (lb == 0 || (na * cols) % (kTile >> lb) == 0);
+        if (!fits) {
+            const size_t n = static_cast<size_t>(1) << log2n;
+            void *tv = nullptr;
+            if (int rc = workspace(WS_SCRATCH_B, n * cols * sizeof(c32), &tv)) return rc;
+            float2 *t = static_cast<float2 *>(tv);
+            if (int rc = launch_transpose_blocks(in_f2, t, 1, n, cols, s)) return rc;   // t[col][row]
+            if (int rc = launch_fft_batch(t, t, log2n, cols, direction, s)) return rc;  // in place (scratch slot A above 2^14)
+            return launch_transpose_blocks(t, out_f2, 1, cols, n, s);                   // out[row][col]
+        }
+    }
     if (log2n <= 8) {
         const size_t n = static_cast<size_t>(1) << log2n;
         const ColumnPlan p{cols, cols, 0, cols, 0};

@@ -917,8 +917,7 @@ int launch_fir_direct(const float *x, float *y, size_t channels, size_t n, const
     auto kern = slots > 1 ? (aligned ? fir_direct_kernel<true, true> : fir_direct_kernel<false, true>)
                           : (aligned ? fir_direct_kernel<true, false> : fir_direct_kernel<false, false>);
     if (lds_bytes > 64 * 1024)
-        DSPGPU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       static_cast<int>(lds_bytes)));
+        if (int rc = allow_full_lds(reinterpret_cast<const void *>(kern))) return rc;
     hipLaunchKernelGGL(kern, dim3(blocks, groups), dim3(kFirThreads), lds_bytes, s, x, y, n, channels, d_taps, ntaps, Q, slots, S,
                        hist, zero_head);
     return check_launch("fir_direct_kernel");
@@ -974,10 +973,7 @@ int launch_os(const float *x, float *y, size_t channels, size_t n, const c32 *d_
         const dim3 wgrid(static_cast<unsigned>(wgs));
 #define DSPGPU_OSW_CASE(I0)                                                                                              \
     case I0: {                                                                                                          \
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(fir_os_wave_kernel<I0>),      \
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize,                  \
-                                                           static_cast<int>(kOsWaveLdsBytes));                          \
-        if (attr != hipSuccess) return fail(DSP_GPU_EHIP, "fir_os_wave_kernel: LDS attribute: %s", hipGetErrorString(attr)); \
+        if (int rc = allow_full_lds(reinterpret_cast<const void *>(fir_os_wave_kernel<I0>))) return rc;                 \
         hipLaunchKernelGGL(fir_os_wave_kernel<I0>, wgrid, dim3(kOsWaveThreads), kOsWaveLdsBytes, s, x, y, n, d_hspec, ntaps, \
                            bpc, total_blocks, tiles, chunkw);                                                           \
     } break
@@ -1014,8 +1010,7 @@ int launch_os(const float *x, float *y, size_t channels, size_t n, const c32 *d_
     case 11: DSPGPU_OS_LAUNCH(11, 256); break;
     case 12: DSPGPU_OS_LAUNCH(12, 256); break;
     case 14:
-        DSPGPU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fir_overlap_save_kernel<14>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes)));
+        if (int rc = allow_full_lds(reinterpret_cast<const void *>(fir_overlap_save_kernel<14>))) return rc;
         DSPGPU_OS_LAUNCH(14, 1024);
         break;
     default: return fail(DSP_GPU_EINVAL, "overlap-save FIR: no kernel for 2^%d-point blocks", log2n);
@@ -1068,8 +1063,7 @@ int launch_moving_average(const float *x, float *y, size_t channels, size_t n, i
     }
 #undef DSPGPU_MA_PICK
     if (lds_bytes > 64 * 1024)
-        DSPGPU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       static_cast<int>(lds_bytes)));
+        if (int rc = allow_full_lds(reinterpret_cast<const void *>(kern))) return rc;
     hipLaunchKernelGGL(kern, dim3(blocks, channels), dim3(kThreads), lds_bytes, s, x, y, n, npoints, span, cpt);
     return check_launch("moving_average_kernel");
 }

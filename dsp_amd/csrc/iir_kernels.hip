@@ -26,6 +26,7 @@
 //   iir_carry_kernel   scan of the per-tile end states (one workgroup per channel).
 #include <cmath>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <type_traits>
 #include <vector>
@@ -750,16 +751,61 @@ double feedback_noise_gain(const IirCoef &co) {
     return total;
 }
 
+// What the host works out once per coefficient set (cached): the companion powers and the decisions
+// that follow from them.
+struct ScanPlan {
+    IirCoef co;
+    std::vector<Mat> pow32;  // A^(32*2^j), j = 0..8
+    std::vector<double> hrow;  // [kRow][P]: v[t] of the zero-input run started from the unit state e_i
+    int levels = 0;          // doubling levels whose matrix still matters (norm > 2^-60)
+    int warm = -1;           // smallest multiple of 32 with ||A^W||_inf <= 2^-44 (<= kTile/4), else -1
+    int decay = 0;           // smallest j <= 64 with ||(A^kTile)^j|| <= 2^-60 (0: slower than that)
+    bool wide = false;       // carry states in double-double
+    double predicted = 0.0;  // predicted relative error of the chosen carry arithmetic
+    bool usable = false;
+    unsigned long long serial = 0;  // identifies the plan in the device-table cache
+};
+
+// The matrix table a scan launch reads lives on the device with its plan: built and uploaded ONCE per (plan, carry
+// arithmetic, carry-scan grouping) and device, then only looked up -- a streamed filter no longer pays a host-side
+// rebuild (up to 64 double-double matrix products) and a pageable upload per block.  Entries are never evicted while
+// the library is loaded (a few KB each, at most kMaxTables per device; beyond that a call uploads its own table into
+// the shared workspace slot as before), so a pointer handed to a launch stays valid.
+struct DeviceTable {
+    unsigned long long serial;
+    int wide, g;  // g = 0: fused / local-carry forms (no G-dependent slots)
+    double *ptr;
+    hipEvent_t ready;  // recorded on the uploading stream; other streams wait for it
+    hipStream_t stream;
+};
+constexpr size_t kMaxTables = 256;
+constexpr int kMaxDev = 64;
+std::mutex g_table_mutex;
+std::vector<DeviceTable> g_tables[kMaxDev];
+
+bool tables_in_use(int dev) {
+    std::lock_guard<std::mutex> lock(g_table_mutex);
+    return dev >= 0 && dev < kMaxDev && !g_tables[dev].empty();
+}
+
+void release_tables(int dev) {  // with device `dev` current and idle
+    if (dev < 0 || dev >= kMaxDev) return;
+    std::lock_guard<std::mutex> lock(g_table_mutex);
+    for (DeviceTable &t : g_tables[dev]) {
+        (void)hipFree(t.ptr);
+        (void)hipEventDestroy(t.ready);
+    }
+    g_tables[dev].clear();
+}
+
 template <int P, bool ALIGNED, bool WIDE>
 int scan_launch(const float *x, float *y, size_t channels, size_t n, const IirCoef &co, const double *state_in,
-                double *state, const std::vector<Mat> &pow32, const std::vector<double> &hrow, int levels, int warm,
-                hipStream_t s) {
+                double *state, const ScanPlan &plan, hipStream_t s) {
     constexpr int W = kWords<P, WIDE>;
     const size_t ms = static_cast<size_t>(W) * P;
-    std::vector<double> table(static_cast<size_t>(9 + 9) * ms + hrow.size(), 0.0);  // 18 matrix slots, then hrow[kRow][P]
-    std::copy(hrow.begin(), hrow.end(), table.begin() + 18 * ms);
-    for (int j = 0; j <= kLevels; ++j) store_mat(table, j, pow32[j], P, WIDE);
-    const Mat &MT = pow32[kLevels];  // A^kTile
+    const std::vector<Mat> &pow32 = plan.pow32;
+    const int levels = plan.levels;
+    int warm = plan.warm;
     const bool fused = warm > 0 || n <= static_cast<size_t>(kTile);
     if (warm < 0) warm = 0;
     unsigned ntiles;
@@ -768,15 +814,7 @@ int scan_launch(const float *x, float *y, size_t channels, size_t n, const IirCo
     unsigned G = (ntiles + kCt - 1) / kCt, tiles_per_wg = ntiles, carry_warm = 0;
     int carry_terms = 0;  // > 0: MT^carry_terms is negligible and small: tiles sum their own carries, no carry kernel
     if (!fused) {
-        Mat pw = MT;
-        int decay = 0;  // smallest j <= 64 with ||MT^j|| <= 2^-60 (0: slower than that)
-        for (int j = 1; j <= 64; ++j) {
-            if (mat_norm_inf(pw, P) <= 0x1p-60) {
-                decay = j;
-                break;
-            }
-            pw = mat_mul(pw, MT, P);
-        }
+        const int decay = plan.decay;
         if (decay > 0 && decay <= 2) carry_terms = decay;
         constexpr unsigned kCarryG = 4;  // tiles per thread when the carry scan is cut into workgroups
         if (decay > 0 && ntiles > 4 * kCt * kCarryG) {
@@ -784,18 +822,62 @@ int scan_launch(const float *x, float *y, size_t channels, size_t n, const IirCo
             tiles_per_wg = kCt * kCarryG;  // 1024 >= 64 >= decay
             carry_warm = static_cast<unsigned>(decay);
         }
+    }
+    const int gkey = (fused || carry_terms > 0) ? 0 : static_cast<int>(G);  // only the carry kernel reads the G-dependent slots
+
+    // 18 matrix slots (0..8: A^(32*2^j); 9: MT = A^kTile; 10..: MT^(G*2^j)), then hrow[kRow][P]
+    auto build_table = [&](std::vector<double> &table) {
+        table.assign(static_cast<size_t>(9 + 9) * ms + plan.hrow.size(), 0.0);
+        std::copy(plan.hrow.begin(), plan.hrow.end(), table.begin() + 18 * ms);
+        for (int j = 0; j <= kLevels; ++j) store_mat(table, j, pow32[j], P, WIDE);
+        const Mat &MT = pow32[kLevels];
         store_mat(table, 9, MT, P, WIDE);
-        Mat mg = mat_pow(MT, G, P);
-        for (int j = 0; j < kCtLevels; ++j) {
-            store_mat(table, 10 + j, mg, P, WIDE);
-            mg = mat_mul(mg, mg, P);
+        if (gkey) {
+            Mat mg = mat_pow(MT, G, P);
+            for (int j = 0; j < kCtLevels; ++j) {
+                store_mat(table, 10 + j, mg, P, WIDE);
+                mg = mat_mul(mg, mg, P);
+            }
+        }
+    };
+    double *d_table = nullptr;
+    {
+        int dev = 0;
+        DSPGPU_HIP(hipGetDevice(&dev));
+        if (dev < 0 || dev >= kMaxDev) return fail(DSP_GPU_EUNSUPPORTED, "device index %d out of range", dev);
+        std::lock_guard<std::mutex> lock(g_table_mutex);
+        std::vector<DeviceTable> &tabs = g_tables[dev];
+        for (const DeviceTable &t : tabs)
+            if (t.serial == plan.serial && t.wide == (WIDE ? 1 : 0) && t.g == gkey) {
+                d_table = t.ptr;
+                if (t.stream != s) DSPGPU_HIP(hipStreamWaitEvent(s, t.ready, 0));
+                break;
+            }
+        if (!d_table) {
+            std::vector<double> table;
+            build_table(table);
+            if (tabs.size() < kMaxTables) {
+                DeviceTable t{plan.serial, WIDE ? 1 : 0, gkey, nullptr, nullptr, s};
+                if (hipMalloc(&t.ptr, table.size() * sizeof(double)) != hipSuccess)
+                    return fail(DSP_GPU_ENOMEM, "IIR scan: table allocation failed");
+                // pageable source: the runtime stages the bytes before returning, `table` may go out of scope
+                hipError_t e = hipMemcpyAsync(t.ptr, table.data(), table.size() * sizeof(double), hipMemcpyHostToDevice, s);
+                if (e == hipSuccess) e = hipEventCreateWithFlags(&t.ready, hipEventDisableTiming);
+                if (e == hipSuccess) e = hipEventRecord(t.ready, s);
+                if (e != hipSuccess) {
+                    (void)hipFree(t.ptr);
+                    return fail(DSP_GPU_EHIP, "IIR scan: table upload failed: %s", hipGetErrorString(e));
+                }
+                tabs.push_back(t);
+                d_table = t.ptr;
+            } else {  // cache full: this call's own copy in the shared workspace slot
+                void *d_table_v = nullptr;
+                if (int rc = workspace(WS_IIR_TABLE, table.size() * sizeof(double), &d_table_v)) return rc;
+                d_table = static_cast<double *>(d_table_v);
+                DSPGPU_HIP(hipMemcpyAsync(d_table, table.data(), table.size() * sizeof(double), hipMemcpyHostToDevice, s));
+            }
         }
     }
-    void *d_table_v = nullptr;
-    if (int rc = workspace(WS_IIR_TABLE, table.size() * sizeof(double), &d_table_v)) return rc;
-    double *d_table = static_cast<double *>(d_table_v);
-    // pageable source: the runtime stages the bytes before returning, `table` may go out of scope
-    DSPGPU_HIP(hipMemcpyAsync(d_table, table.data(), table.size() * sizeof(double), hipMemcpyHostToDevice, s));
 
     // persistent: at most kScanWgsPerCu workgroups per CU of an XCD (32 CUs), fewer when there are fewer tiles
     const dim3 grid(ntiles >= 64u ? 8u * std::min((ntiles + 7u) / 8u, 32u * kScanWgsPerCu) : ntiles,
@@ -826,19 +908,6 @@ int scan_launch(const float *x, float *y, size_t channels, size_t n, const IirCo
                        state_in, state, nullptr, tc, ntiles, 0, levels, d_table + 18 * ms, 0);
     return check_launch("iir_scan_kernel<apply>");
 }
-
-// What the host works out once per coefficient set (cached): the companion powers and the decisions
-// that follow from them.
-struct ScanPlan {
-    IirCoef co;
-    std::vector<Mat> pow32;  // A^(32*2^j), j = 0..8
-    std::vector<double> hrow;  // [kRow][P]: v[t] of the zero-input run started from the unit state e_i
-    int levels = 0;          // doubling levels whose matrix still matters (norm > 2^-60)
-    int warm = -1;           // smallest multiple of 32 with ||A^W||_inf <= 2^-44 (<= kTile/4), else -1
-    bool wide = false;       // carry states in double-double
-    double predicted = 0.0;  // predicted relative error of the chosen carry arithmetic
-    bool usable = false;
-};
 
 // Powers of the companion matrix by RUNNING the recursion: column c of A^k is the feedback state after k
 // zero-input steps from the unit state e_c.  Done in double-double this is as well conditioned as the
@@ -883,6 +952,18 @@ void build_plan(const IirCoef &co, ScanPlan &plan) {
             if (nrm <= 0x1p-200) break;  // everything later is zero for all purposes (left as zeros)
         }
     }
+    {  // how fast the tile matrix MT = A^kTile decays: decides how the tile carries are scanned (scan_launch)
+        const Mat &MT = plan.pow32[kLevels];
+        Mat pw = MT;
+        plan.decay = 0;
+        for (int j = 1; j <= 64; ++j) {
+            if (mat_norm_inf(pw, P) <= 0x1p-60) {
+                plan.decay = j;
+                break;
+            }
+            pw = mat_mul(pw, MT, P);
+        }
+    }
     // Conditioning.  A carry S += M S' in double rounds at ||M|| * 2^-53 relative to the state and the
     // recursion amplifies an injected error by the feedback noise gain (calibrated on the 4-pole
     // Chebyshev at fc = 0.01: predicted 5e-5, measured 5.4e-5 with double carries).  Direct-form
@@ -897,19 +978,20 @@ void build_plan(const IirCoef &co, ScanPlan &plan) {
 }
 
 std::mutex g_plan_mutex;
-std::vector<ScanPlan> g_plans;  // small cache: a filter is usually applied many times
+std::vector<std::shared_ptr<const ScanPlan>> g_plans;  // small cache: a filter is usually applied many times
+unsigned long long g_plan_serial = 0;
 
-const ScanPlan *cached_plan(const IirCoef &co, ScanPlan &local) {
+std::shared_ptr<const ScanPlan> cached_plan(const IirCoef &co) {
     std::lock_guard<std::mutex> lock(g_plan_mutex);
-    for (const ScanPlan &p : g_plans)
-        if (p.co.poles == co.poles && std::memcmp(p.co.a, co.a, sizeof co.a) == 0 && std::memcmp(p.co.b, co.b, sizeof co.b) == 0) {
-            local = p;  // copy out: the cache may be rotated by another thread
-            return &local;
-        }
-    build_plan(co, local);
-    if (g_plans.size() >= 16) g_plans.erase(g_plans.begin());
-    g_plans.push_back(local);
-    return &local;
+    for (const auto &p : g_plans)
+        if (p->co.poles == co.poles && std::memcmp(p->co.a, co.a, sizeof co.a) == 0 && std::memcmp(p->co.b, co.b, sizeof co.b) == 0)
+            return p;  // shared: the cache may be rotated by another thread while this call runs
+    auto plan = std::make_shared<ScanPlan>();
+    build_plan(co, *plan);
+    plan->serial = ++g_plan_serial;
+    if (g_plans.size() >= 64) g_plans.erase(g_plans.begin());
+    g_plans.push_back(plan);
+    return plan;
 }
 
 template <int P, bool ALIGNED>
@@ -920,12 +1002,11 @@ int scan_dispatch(const float *x, float *y, size_t channels, size_t n, const Iir
         if (int rc = scan_dispatch<P, ALIGNED>(x, y, kMaxGridY, n, co, state, s)) return rc;
         if (state) state += kMaxGridY * 2 * P;
     }
-    ScanPlan plan;
-    cached_plan(co, plan);
-    if (!plan.usable)
+    const std::shared_ptr<const ScanPlan> plan = cached_plan(co);
+    if (!plan->usable)
         return fail(DSP_GPU_EUNSUPPORTED,
                     "IIR scan: filter too ill-conditioned for block-parallel carries "
-                    "(predicted relative error %.2e > 1e-4); use DSP_GPU_IIR_BATCH", plan.predicted);
+                    "(predicted relative error %.2e > 1e-4); use DSP_GPU_IIR_BATCH", plan->predicted);
     // tile 0 reads the caller's history while the last tile writes the new one: read from a snapshot
     const double *state_in = state;
     if (state) {
@@ -935,8 +1016,8 @@ int scan_dispatch(const float *x, float *y, size_t channels, size_t n, const Iir
         DSPGPU_HIP(hipMemcpyAsync(snap, state, sb, hipMemcpyDeviceToDevice, s));
         state_in = static_cast<const double *>(snap);
     }
-    return plan.wide ? scan_launch<P, ALIGNED, true>(x, y, channels, n, co, state_in, state, plan.pow32, plan.hrow, plan.levels, plan.warm, s)
-                     : scan_launch<P, ALIGNED, false>(x, y, channels, n, co, state_in, state, plan.pow32, plan.hrow, plan.levels, plan.warm, s);
+    return plan->wide ? scan_launch<P, ALIGNED, true>(x, y, channels, n, co, state_in, state, *plan, s)
+                      : scan_launch<P, ALIGNED, false>(x, y, channels, n, co, state_in, state, *plan, s);
 }
 
 template <int P, bool ALIGNED>
@@ -963,6 +1044,9 @@ bool is_aligned(const float *x, const float *y, size_t n) {
 }
 
 }  // namespace
+
+bool iir_tables_in_use(int dev) { return tables_in_use(dev); }
+void release_iir_tables(int dev) { release_tables(dev); }
 
 int launch_iir_batch(const float *x, float *y, size_t channels, size_t n, const IirCoef &co, double *state,
                      const IirPerChannel *pc, hipStream_t s) {

@@ -115,9 +115,18 @@ class NativePlan:
             capi.check(capi.lib().dsp_gpu_fft_dist_plan_create_rccl(C.byref(self._handle), log2n, rank, world, nccl_comm))
         else:
             # keep the ctypes thunk alive as long as the plan: the library calls it from dsp_gpu_fft_dist
-            self._thunk = capi.EXCHANGE_FN(
-                (lambda user, send, recv, nbytes, w, stream: int(exchange(send, recv, nbytes, w, stream)))
-                if exchange is not None else 0)
+            self._error = None
+
+            def thunk(user, send, recv, nbytes, w, stream):
+                # an exception must not escape into C (ctypes would report it as "unraisable" and hand the library a 0 =
+                # success, which then transforms buffers that were never filled): keep it, fail the call, re-raise in run()
+                try:
+                    return int(exchange(send, recv, nbytes, w, stream))
+                except BaseException as e:  # noqa: BLE001
+                    self._error = e
+                    return capi.EHIP
+
+            self._thunk = capi.EXCHANGE_FN(thunk if exchange is not None else 0)
             capi.check(capi.lib().dsp_gpu_fft_dist_plan_create(C.byref(self._handle), log2n, rank, world, self._thunk, None))
         self.local_points = capi.lib().dsp_gpu_fft_dist_local_points(self._handle)
 
@@ -135,8 +144,11 @@ class NativePlan:
         if t.numel() != self.local_points:
             raise ValueError("x_local must hold N / world points")
         out = self.torch.empty_like(t) if out is None else out
-        self.capi.check(self.capi.lib().dsp_gpu_fft_dist(self._handle, t.data_ptr(), out.data_ptr(), int(inverse),
-                                                         self._stream(t)))
+        rc = self.capi.lib().dsp_gpu_fft_dist(self._handle, t.data_ptr(), out.data_ptr(), int(inverse), self._stream(t))
+        err, self._error = getattr(self, "_error", None), None
+        if err is not None:
+            raise err
+        self.capi.check(rc)
         return out
 
     def close(self):

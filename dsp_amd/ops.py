@@ -59,6 +59,40 @@ def _ptr(a):
     return a.data_ptr() if _is_torch(a) else a.ctypes.data
 
 
+def _out(out, x, shape, dtype_np, dtype_torch_name):
+    """The output buffer: a fresh one, or the caller's after the checks the kernels rely on (they write `count`
+    elements through a raw pointer: same kind of container and device as x, dtype, size, contiguity)."""
+    if out is None:
+        return _empty_like(x, shape, dtype_np, dtype_torch_name)
+    count = int(np.prod(shape))
+    if _is_torch(out) != _is_torch(x):
+        raise capi.DspGpuError(capi.EINVAL, "out must live where x lives (torch tensor with torch, numpy with numpy)")
+    if _is_torch(out):
+        ok = (out.device == x.device and out.dtype == getattr(torch, dtype_torch_name) and out.numel() == count
+              and out.is_contiguous())
+    else:
+        ok = out.dtype == dtype_np and out.size == count and out.flags.c_contiguous and out.flags.writeable
+    if not ok:
+        raise capi.DspGpuError(capi.EINVAL, f"out must be a contiguous {dtype_torch_name} buffer of {count} elements on x's device")
+    return out
+
+
+class _on_device:
+    """Runs the C call with x's GPU current: the library takes its workspaces and tables from hipGetDevice()."""
+
+    def __init__(self, x):
+        self._ctx = torch.cuda.device(x.device) if _is_torch(x) and x.is_cuda else None
+
+    def __enter__(self):
+        if self._ctx is not None:
+            self._ctx.__enter__()
+
+    def __exit__(self, *exc):
+        if self._ctx is not None:
+            return self._ctx.__exit__(*exc)
+        return False
+
+
 def fft0(x, inverse: bool = False, out=None):
     """Batched complex FFT over the last axis (length 2^k, k in 1..30).  fft.h:31-55."""
     x, px, mem = _prep(x, np.complex64, "complex64")
@@ -67,10 +101,10 @@ def fft0(x, inverse: bool = False, out=None):
     if n < 2 or (1 << log2n) != n:
         raise capi.DspGpuError(capi.EINVAL, f"transform length {n} is not a power of two >= 2")
     batch = int(np.prod(x.shape[:-1])) if x.ndim > 1 else 1
-    if out is None:
-        out = _empty_like(x, tuple(x.shape), np.complex64, "complex64")
-    capi.check(capi.lib().dsp_gpu_fft_batch(px, _ptr(out), log2n, batch, capi.INVERSE if inverse else capi.FORWARD,
-                                            mem, _stream_of(x)))
+    out = _out(out, x, tuple(x.shape), np.complex64, "complex64")
+    with _on_device(x):
+        capi.check(capi.lib().dsp_gpu_fft_batch(px, _ptr(out), log2n, batch, capi.INVERSE if inverse else capi.FORWARD,
+                                                mem, _stream_of(x)))
     return out
 
 
@@ -81,9 +115,10 @@ def fft(x, nf: int, inverse: bool = False, shift: bool = False):
     batch = int(np.prod(x.shape[:-1])) if x.ndim > 1 else 1
     log2n = max(1, int(np.ceil(np.log2(nf))))
     out = _empty_like(x, tuple(x.shape[:-1]) + (1 << log2n,), np.complex64, "complex64")
-    capi.check(capi.lib().dsp_gpu_fft_real_batch(px, n_in, n_in, _ptr(out), int(nf), batch,
-                                                 capi.INVERSE if inverse else capi.FORWARD, int(shift), mem,
-                                                 _stream_of(x)))
+    with _on_device(x):
+        capi.check(capi.lib().dsp_gpu_fft_real_batch(px, n_in, n_in, _ptr(out), int(nf), batch,
+                                                     capi.INVERSE if inverse else capi.FORWARD, int(shift), mem,
+                                                     _stream_of(x)))
     return out
 
 
@@ -98,9 +133,10 @@ def convolve(x, taps, mode: str = "auto", out=None):
     taps = np.ascontiguousarray(taps, dtype=np.float32)  # the designers produce double; the device runs fp32
     n = x.shape[-1]
     channels = int(np.prod(x.shape[:-1])) if x.ndim > 1 else 1
-    y = out if out is not None else _empty_like(x, tuple(x.shape), np.float32, "float32")
-    capi.check(capi.lib().dsp_gpu_convolve(px, _ptr(y), channels, n, taps.ctypes.data, taps.size, _MODES[mode], mem,
-                                           _stream_of(x)))
+    y = _out(out, x, tuple(x.shape), np.float32, "float32")
+    with _on_device(x):
+        capi.check(capi.lib().dsp_gpu_convolve(px, _ptr(y), channels, n, taps.ctypes.data, taps.size, _MODES[mode], mem,
+                                               _stream_of(x)))
     return y
 
 
@@ -119,10 +155,11 @@ def convolve_stream(x, taps, history, position: int, mode: str = "direct", out=N
         else (history.flags.c_contiguous and history.dtype == np.float32 and history.size == want)
     if not ok:
         raise capi.DspGpuError(capi.EINVAL, "history must be contiguous fp32 [channels, ntaps-1]")
-    y = out if out is not None else _empty_like(x, tuple(x.shape), np.float32, "float32")
-    capi.check(capi.lib().dsp_gpu_convolve_stream(px, _ptr(y), channels, n, taps.ctypes.data, taps.size,
-                                                  _ptr(history) if want else None, int(position), _MODES[mode], mem,
-                                                  _stream_of(x)))
+    y = _out(out, x, tuple(x.shape), np.float32, "float32")
+    with _on_device(x):
+        capi.check(capi.lib().dsp_gpu_convolve_stream(px, _ptr(y), channels, n, taps.ctypes.data, taps.size,
+                                                      _ptr(history) if want else None, int(position), _MODES[mode], mem,
+                                                      _stream_of(x)))
     return y
 
 
@@ -131,8 +168,9 @@ def moving_average(x, npoints: int, out=None):
     x, px, mem = _prep(x, np.float32, "float32")
     n = x.shape[-1]
     channels = int(np.prod(x.shape[:-1])) if x.ndim > 1 else 1
-    y = out if out is not None else _empty_like(x, tuple(x.shape), np.float32, "float32")
-    capi.check(capi.lib().dsp_gpu_moving_average(px, _ptr(y), channels, n, int(npoints), mem, _stream_of(x)))
+    y = _out(out, x, tuple(x.shape), np.float32, "float32")
+    with _on_device(x):
+        capi.check(capi.lib().dsp_gpu_moving_average(px, _ptr(y), channels, n, int(npoints), mem, _stream_of(x)))
     return y
 
 
@@ -152,7 +190,7 @@ def iir(x, a, b, c0: float = 1.0, d0: float = 0.0, state=None, mode: str = "auto
     poles = a.size - 1
     n = x.shape[-1]
     channels = int(np.prod(x.shape[:-1])) if x.ndim > 1 else 1
-    y = out if out is not None else _empty_like(x, tuple(x.shape), np.float32, "float32")
+    y = _out(out, x, tuple(x.shape), np.float32, "float32")
     pstate = None
     if state is not None:
         if _is_torch(state) != _is_torch(x):
@@ -163,8 +201,9 @@ def iir(x, a, b, c0: float = 1.0, d0: float = 0.0, state=None, mode: str = "auto
         elif not (state.flags.c_contiguous and state.dtype == np.float64 and state.size == channels * 2 * poles):
             raise capi.DspGpuError(capi.EINVAL, "state must be contiguous float64 [channels, 2*poles]")
         pstate = _ptr(state)
-    capi.check(capi.lib().dsp_gpu_iir(px, _ptr(y), channels, n, a.ctypes.data, b.ctypes.data, poles, float(c0),
-                                      float(d0), pstate, _IIR_MODES[mode], mem, _stream_of(x)))
+    with _on_device(x):
+        capi.check(capi.lib().dsp_gpu_iir(px, _ptr(y), channels, n, a.ctypes.data, b.ctypes.data, poles, float(c0),
+                                          float(d0), pstate, _IIR_MODES[mode], mem, _stream_of(x)))
     return y
 
 
@@ -191,9 +230,10 @@ def iir_multi(x, a, b, c0=None, d0=None, state=None, out=None):
     pa, pb = chk(a, channels * (poles + 1), "a"), chk(b, channels * (poles + 1), "b")
     pc0, pd0 = chk(c0, channels, "c0"), chk(d0, channels, "d0")
     pstate = chk(state, channels * 2 * poles, "state")
-    y = out if out is not None else _empty_like(x, tuple(x.shape), np.float32, "float32")
-    capi.check(capi.lib().dsp_gpu_iir_multi(px, _ptr(y), channels, n, pa, pb, poles, pc0, pd0, pstate, mem,
-                                            _stream_of(x)))
+    y = _out(out, x, tuple(x.shape), np.float32, "float32")
+    with _on_device(x):
+        capi.check(capi.lib().dsp_gpu_iir_multi(px, _ptr(y), channels, n, pa, pb, poles, pc0, pd0, pstate, mem,
+                                                _stream_of(x)))
     return y
 
 

@@ -20,8 +20,16 @@
  *     last failure on the calling thread.
  *   - the caller owns every buffer it passes.  The library owns per-device workspaces
  *     and cached tap uploads, released by dsp_gpu_shutdown().
- *   - re-entrant; intended multi-GPU use is one host thread (or process) per device with
- *     that device made current (hipSetDevice) before the call.
+ *   - intended multi-GPU use is one host thread (or process) per device with that device made
+ *     current (hipSetDevice) before the call.  Thread-safe in the sense that the library's own tables
+ *     (tap cache, IIR plans) are locked and handed out pinned; but the per-device WORKSPACES are shared,
+ *     not keyed per stream, so calls that use one must not overlap on one device (from two threads or
+ *     two streams): every DSP_GPU_MEM_HOST call (staging), FFTs above 2^14 points, dsp_gpu_fft_columns,
+ *     dsp_gpu_fft_rows_exchange, dsp_gpu_convolve_stream (history scratch), dsp_gpu_iir with `state` or in
+ *     a SCAN form that carries tile states, dsp_gpu_iir_multi from host memory, and
+ *     dsp_gpu_fft_batch_noalloc (its fixed array).  Calls that touch no workspace -- device-pointer FFTs up
+ *     to 2^14 points, dsp_gpu_convolve, dsp_gpu_moving_average, dsp_gpu_iir BATCH without state -- may run
+ *     concurrently on different streams.
  */
 #ifndef DSP_GPU_H
 #define DSP_GPU_H
@@ -174,7 +182,9 @@ int dsp_gpu_iir_multi(const float *x, float *y, size_t channels, size_t n, const
  * dsp_gpu_fft_dist (below) sequences around its three all-to-all exchanges.  DEVICE pointers
  * only, asynchronous on `stream`, complex fp32 interleaved, in != out.
  *   dsp_gpu_fft_columns       FFT along axis 0 of a row-major [2^log2n][cols] matrix, natural order,
- *                             4 <= log2n <= 16, cols a multiple of 256 (16 when log2n <= 8)
+ *                             4 <= log2n <= 16, any cols >= 1.  Column passes (one or two HBM trips) when cols is a
+ *                             multiple of the column tile -- 4096 / 2^log2n for log2n <= 8, else 4096 / 2^floor(log2n/2)
+ *                             -- and transpose -> row transforms -> transpose through a library workspace otherwise
  *   dsp_gpu_swap_axes         out[b][a][c] = in[a][b][c]; when tw_log2n > 0 each element is also
  *                             multiplied by W^{(tw_row0 + b) * (a*c_extent + c)}, W = e^{+-2 pi i / 2^tw_log2n}
  *                             (sign by `direction`): the inter-step twiddle fused into the unpack

@@ -358,3 +358,58 @@ def test_native_plan_rccl_world_of_one(dev, orc):
     finally:
         torch.cuda.synchronize()
         comm.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("log2n", list(range(8, 16)))
+def test_small_plans_every_world(orc, dev, log2n):
+    """Every shape dsp_gpu_fft_dist_plan_create accepts must also run: small transforms on many ranks leave fewer
+    columns per rank than a column-pass tile (2^10 on one rank: 32 against 128; 2^14 on 8 ranks: 16 against 32) and
+    take dsp_gpu_fft_columns' transpose route.  Plans the shape rules refuse must fail at creation."""
+    import torch
+    from dsp_amd import capi, dist_fft
+    x = _signal(log2n, seed=100 + log2n)
+    for world in (1, 2, 4, 8):
+        l1 = (log2n + 1) // 2
+        n1, n2 = 1 << l1, 1 << (log2n - l1)
+        if n1 % world or n2 % world or n2 // world < 2:
+            with pytest.raises(capi.DspGpuError):
+                dist_fft.NativePlan(log2n, 0, world)
+            continue
+        for inverse in (False, True):
+            parts = [torch.from_numpy(p.copy()).to(dev) for p in np.split(x, world)]
+            got = torch.cat(dist_fft.simulate(parts, log2n, inverse)).cpu().numpy()
+            assert rel_l2(got, orc.fft0(x.astype(np.complex128), inverse)) <= 1e-5 * log2n, (log2n, world, inverse)
+
+
+@pytest.mark.gpu
+def test_fft_columns_any_width(dev):
+    import torch
+    from dsp_amd import dist_fft
+    g, ref = dist_fft.GpuLocalOps(), NumpyLocalOps()
+    rng = np.random.default_rng(77)
+    for n, cols in ((16, 2), (64, 24), (256, 1), (512, 6), (1024, 32), (4096, 10), (16384, 16), (65536, 2)):
+        x = (rng.standard_normal(n * cols) + 1j * rng.standard_normal(n * cols)).astype(np.complex64)
+        for inv in (False, True):
+            got = g.fft_columns(torch.from_numpy(x).to(dev), n, cols, inv).cpu().numpy()
+            want = ref.fft_columns(torch.from_numpy(x), n, cols, inv).numpy()
+            assert rel_l2(got, want) <= 1e-5 * np.log2(n), (n, cols, inv)
+
+
+@pytest.mark.gpu
+def test_exchange_callback_exception_propagates(dev):
+    """A Python exchange that raises must fail the transform (not return success on unfilled buffers)."""
+    import torch
+    from dsp_amd import dist_fft
+
+    class Boom(RuntimeError):
+        pass
+
+    def exchange(send, recv, nbytes, world, stream):
+        raise Boom("exchange failed")
+
+    plan = dist_fft.NativePlan(16, 0, 1, exchange=exchange)
+    x = torch.zeros(1 << 16, dtype=torch.complex64, device=dev)
+    with pytest.raises(Boom):
+        plan.run(x)
+    plan.close()

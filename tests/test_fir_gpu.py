@@ -367,3 +367,61 @@ def test_overlap_save_wave_kernel(ops, dev, orc, channels, n, ntaps, monkeypatch
     monkeypatch.setenv("DSP_GPU_OS_WAVE_MIN_TILES", "999999999")
     other = ops.convolve(xd, h, "overlap_save").cpu().numpy()
     assert rel_l2(g[1:-1], other) <= 5e-6
+
+
+@pytest.mark.gpu
+def test_tap_cache_many_sets_without_device_sync(ops, dev, orc):
+    """300 distinct tap sets streamed through dsp_gpu_convolve_stream (more than the 256 cache slots: the least
+    recently used slots are taken over).  While they run a second stream is kept busy for much longer: were any
+    call to synchronise the whole device (the old flush-all did), it would return only after that stream had
+    drained.  Results are checked for the first, a middle and the last set, and for a re-used early one."""
+    import time
+    import torch
+    rng = np.random.default_rng(300)
+    ntaps, channels, n = 63, 4, 2048
+    sets = [rng.standard_normal(ntaps) / 8 for _ in range(300)]
+    x = rng.standard_normal((channels, n)).astype(np.float32)
+    xd = torch.from_numpy(x).to(dev)
+    hist = torch.zeros(channels, ntaps - 1, device=dev)
+    ops.convolve_stream(xd, sets[0], hist, 0, "overlap_save")  # warm up: kernels loaded
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream(device=dev)
+    a = torch.randn(8192, 8192, device=dev)
+    done = torch.cuda.Event()
+    with torch.cuda.stream(side):
+        for _ in range(150):  # >= 1 s of matrix products
+            a = (a @ a) * 1e-4
+        done.record(side)
+    t0 = time.perf_counter()
+    outs = {}
+    for k, h in enumerate(sets):
+        hist.zero_()
+        y = ops.convolve_stream(xd, h, hist, 0, "overlap_save" if k % 2 else "direct")
+        if k in (0, 150, 299):
+            outs[k] = y
+    y_again = ops.convolve_stream(xd, sets[3], torch.zeros_like(hist), 0, "direct")  # evicted by now: uploaded again
+    host_s = time.perf_counter() - t0
+    still_busy = not done.query()
+    torch.cuda.synchronize()
+    assert still_busy, f"the side stream drained while 300 tap sets were issued ({host_s:.3f} s): a device-wide sync?"
+    for k, y in outs.items():
+        assert rel_l2(y.cpu().numpy(), orc.fir(x.astype(np.float64), sets[k])) <= OS_TOL
+    assert rel_l2(y_again.cpu().numpy(), orc.fir(x.astype(np.float64), sets[3])) <= DIRECT_TOL
+
+
+@pytest.mark.gpu
+def test_out_argument_is_validated(ops, dev):
+    import torch
+    from dsp_amd import capi
+    x = torch.zeros(4, 1024, device=dev)
+    h = np.ones(5)
+    for bad in (torch.empty(4, 1000, device=dev), torch.empty(4, 1024, device=dev, dtype=torch.float64),
+                torch.empty(4, 2048, device=dev)[:, ::2], np.empty((4, 1024), np.float32)):
+        with pytest.raises(capi.DspGpuError):
+            ops.convolve(x, h, "direct", out=bad)
+        with pytest.raises(capi.DspGpuError):
+            ops.moving_average(x, 5, out=bad)
+        with pytest.raises(capi.DspGpuError):
+            ops.iir(x, [0.5, 0.0], [0.0, 0.5], out=bad)
+    with pytest.raises(capi.DspGpuError):
+        ops.fft0(torch.zeros(4, 1024, dtype=torch.complex64, device=dev), out=torch.empty(4, 512, dtype=torch.complex64, device=dev))

@@ -362,3 +362,28 @@ def test_aliasing_rules(ops, dev, orc):
         ops.moving_average(big[:210000].view(3, 70000), 5, out=big[4:210004].view(3, 70000))
     h = np.ascontiguousarray(x.cpu().numpy())
     assert np.array_equal(ops.iir(h, a, b, mode="scan", out=h), ops.iir(x, a, b, mode="scan").cpu().numpy())  # host buffers are staged
+
+
+@pytest.mark.gpu
+def test_scan_tables_cached_per_plan_across_streams(dev, orc):
+    """The scan's matrix table lives on the device with its plan: repeated calls, two coefficient sets taking
+    turns and a second stream (which has to wait for the upload made on the first) all read the right one."""
+    import torch
+    from dsp_amd import design, ops
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal((2, 1 << 16)).astype(np.float32)
+    xd = torch.from_numpy(x).to(dev)
+    filters = [design.chebyshev(0.1, 4, highpass=False), design.chebyshev(0.03, 4, highpass=False),
+               design.chebyshev(0.01, 4, highpass=False), design.chebyshev(0.2, 2, highpass=True)]
+    want = [orc.iir(x.astype(np.float64), a, b) for a, b in filters]
+    side = torch.cuda.Stream(device=dev)
+    for rounds in range(3):
+        for k, (a, b) in enumerate(filters):
+            if (k + rounds) % 2:
+                side.wait_stream(torch.cuda.current_stream(dev))
+                with torch.cuda.stream(side):
+                    got = ops.iir(xd, a, b, mode="scan")
+                side.synchronize()
+            else:
+                got = ops.iir(xd, a, b, mode="scan")
+            assert rel_l2(got.cpu().numpy(), want[k]) <= TOL, (rounds, k)
