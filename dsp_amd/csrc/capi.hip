@@ -203,6 +203,15 @@ int stage_out(void *host, size_t out_bytes, hipStream_t s, const HostStage &hs) 
 
 bool bad_mem(int mem) { return mem != DSP_GPU_MEM_HOST && mem != DSP_GPU_MEM_DEVICE; }
 
+// The pipelined host route (host_path.hip): `f(d_in, d_out, unit0, count)` runs the device-pointer form on a chunk.
+template <class F>
+int host_route(const void *in, size_t in_unit, size_t in_total, void *out, size_t out_unit, size_t units, hipStream_t s, F f,
+               void *aux = nullptr, size_t aux_bytes = 0) {
+    HostJob job{static_cast<const char *>(in), in_unit, in_total, static_cast<char *>(out), out_unit, units, aux, aux_bytes,
+                [f](const void *din, void *dout, size_t u0, size_t count, void *daux) { return f(din, dout, u0, count, daux); }};
+    return run_host_job(job, s);
+}
+
 }  // namespace
 
 int workspace(WorkspaceSlot slot, size_t bytes, void **ptr) {
@@ -246,7 +255,7 @@ void release_all_workspaces() {
     int saved = 0, count = 0;
     if (hipGetDevice(&saved) != hipSuccess || hipGetDeviceCount(&count) != hipSuccess) return;
     for (int d = 0; d < count && d < kMaxDevices; ++d) {
-        bool used = iir_tables_in_use(d);
+        bool used = iir_tables_in_use(d) || host_pipe_in_use(d);
         {
             std::lock_guard<std::mutex> lock(g_mutex);
             DeviceState &st = g_dev[d];
@@ -257,6 +266,7 @@ void release_all_workspaces() {
         if (hipSetDevice(d) != hipSuccess) continue;
         (void)hipDeviceSynchronize();
         release_iir_tables(d);
+        release_host_pipes(d);
         std::lock_guard<std::mutex> lock(g_mutex);
         DeviceState &st = g_dev[d];
         for (Buffer &b : st.ws) {
@@ -292,12 +302,10 @@ int dsp_gpu_fft_batch(const void *in, void *out, int log2n, size_t batch, int di
     const size_t bytes = (batch << log2n) * sizeof(float2);
     if (mem == DSP_GPU_MEM_DEVICE)
         return launch_fft_batch(static_cast<const float2 *>(in), static_cast<float2 *>(out), log2n, batch, direction, s);
-    HostStage hs;
-    if (int rc = stage_in(in, bytes, bytes, s, &hs)) return rc;
-    if (int rc = launch_fft_batch(static_cast<const float2 *>(hs.d_in), static_cast<float2 *>(hs.d_out), log2n, batch,
-                                  direction, s))
-        return rc;
-    return stage_out(out, bytes, s, hs);
+    const size_t unit = sizeof(float2) << log2n;
+    return host_route(in, unit, bytes, out, unit, batch, s, [=](const void *din, void *dout, size_t, size_t count, void *) {
+        return launch_fft_batch(static_cast<const float2 *>(din), static_cast<float2 *>(dout), log2n, count, direction, s);
+    });
 }
 
 int dsp_gpu_fft_batch_noalloc(const void *in, void *out, int log2n, size_t batch, int direction, void *stream) {
@@ -351,12 +359,12 @@ int dsp_gpu_fft_real_batch(const float *in, size_t n_in, size_t in_stride, void 
         return launch_fft_real_batch(in, n_in, in_stride, static_cast<float2 *>(out), log2n, batch, direction, shifted, s);
     const size_t in_bytes = ((batch - 1) * in_stride + n_in) * sizeof(float);
     const size_t out_bytes = (batch << log2n) * sizeof(float2);
-    HostStage hs;
-    if (int rc = stage_in(in, in_bytes ? in_bytes : sizeof(float), out_bytes, s, &hs)) return rc;
-    if (int rc = launch_fft_real_batch(static_cast<const float *>(hs.d_in), n_in, in_stride,
-                                       static_cast<float2 *>(hs.d_out), log2n, batch, direction, shifted, s))
-        return rc;
-    return stage_out(out, out_bytes, s, hs);
+    (void)out_bytes;
+    return host_route(in, in_stride * sizeof(float), in_bytes, out, sizeof(float2) << log2n, batch, s,
+                      [=](const void *din, void *dout, size_t, size_t count, void *) {
+                          return launch_fft_real_batch(static_cast<const float *>(din), n_in, in_stride,
+                                                       static_cast<float2 *>(dout), log2n, count, direction, shifted, s);
+                      });
 }
 
 // shared by the one-shot and the streaming form; `history` == nullptr: one-shot (filter.h:123-140)
@@ -392,6 +400,15 @@ static int convolve_impl(const char *who, const float *x, float *y, size_t chann
         mode = os_wanted ? DSP_GPU_CONV_OVERLAP_SAVE : DSP_GPU_CONV_DIRECT;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t bytes = channels * n * sizeof(float);
+    if (mem == DSP_GPU_MEM_HOST && !history) {
+        // one-shot filters: channels are independent, so the batch is pipelined in chunks of channels (mode is resolved
+        // above: every chunk filters the same way)
+        const size_t row = n * sizeof(float);
+        return host_route(x, row, bytes, y, row, channels, s, [=](const void *din, void *dout, size_t, size_t count, void *) {
+            return convolve_impl(who, static_cast<const float *>(din), static_cast<float *>(dout), count, n, taps, ntaps, nullptr, 0,
+                                 mode, DSP_GPU_MEM_DEVICE, stream);
+        });
+    }
     if (partitioned) {
         const float *dx = x;
         float *dy = y;
@@ -476,12 +493,10 @@ int dsp_gpu_moving_average(const float *x, float *y, size_t channels, size_t n, 
     if (device_overlap(x, y, bytes, mem))
         return fail(DSP_GPU_EINVAL, "dsp_gpu_moving_average: x and y overlap (not in-place on device buffers)");
     if (mem == DSP_GPU_MEM_DEVICE) return launch_moving_average(x, y, channels, n, npoints, s);
-    HostStage hs;
-    if (int rc = stage_in(x, bytes, bytes, s, &hs)) return rc;
-    if (int rc = launch_moving_average(static_cast<const float *>(hs.d_in), static_cast<float *>(hs.d_out), channels, n,
-                                       npoints, s))
-        return rc;
-    return stage_out(y, bytes, s, hs);
+    const size_t row = n * sizeof(float);
+    return host_route(x, row, bytes, y, row, channels, s, [=](const void *din, void *dout, size_t, size_t count, void *) {
+        return launch_moving_average(static_cast<const float *>(din), static_cast<float *>(dout), count, n, npoints, s);
+    });
 }
 
 int dsp_gpu_iir(const float *x, float *y, size_t channels, size_t n, const double *a, const double *b, int poles,
@@ -517,31 +532,25 @@ int dsp_gpu_iir(const float *x, float *y, size_t channels, size_t n, const doubl
         mode = DSP_GPU_IIR_BATCH;
     }
     const size_t state_bytes = channels * 2 * static_cast<size_t>(poles) * sizeof(double);
-    const float *dx = x;
-    float *dy = y;
-    double *dstate = state;
-    HostStage hs;
-    if (mem == DSP_GPU_MEM_HOST) {
-        if (int rc = stage_in(x, bytes, bytes, s, &hs)) return rc;
-        dx = static_cast<const float *>(hs.d_in);
-        dy = static_cast<float *>(hs.d_out);
-        if (state) {
-            void *p = nullptr;
-            if (int rc = workspace(WS_STATE, state_bytes, &p)) return rc;
-            dstate = static_cast<double *>(p);
-            DSPGPU_HIP(hipMemcpyAsync(dstate, state, state_bytes, hipMemcpyHostToDevice, s));
-        }
-    }
-    int rc = mode == DSP_GPU_IIR_SCAN ? launch_iir_scan(dx, dy, channels, n, co, dstate, s)
-                                      : launch_iir_batch(dx, dy, channels, n, co, dstate, nullptr, s);
-    if (rc == DSP_GPU_EUNSUPPORTED && auto_mode && mode == DSP_GPU_IIR_SCAN)  // ill-conditioned for the scan
-        rc = launch_iir_batch(dx, dy, channels, n, co, dstate, nullptr, s);
-    if (rc) return rc;
-    if (mem == DSP_GPU_MEM_HOST) {
-        if (state) DSPGPU_HIP(hipMemcpyAsync(state, dstate, state_bytes, hipMemcpyDeviceToHost, s));
-        return stage_out(y, bytes, s, hs);
-    }
-    return DSP_GPU_OK;
+    auto run = [=](const float *dx, float *dy, size_t count, double *dstate) {
+        int rc = mode == DSP_GPU_IIR_SCAN ? launch_iir_scan(dx, dy, count, n, co, dstate, s)
+                                          : launch_iir_batch(dx, dy, count, n, co, dstate, nullptr, s);
+        if (rc == DSP_GPU_EUNSUPPORTED && auto_mode && mode == DSP_GPU_IIR_SCAN)  // ill-conditioned for the scan
+            rc = launch_iir_batch(dx, dy, count, n, co, dstate, nullptr, s);
+        return rc;
+    };
+    if (mem == DSP_GPU_MEM_DEVICE) return run(x, y, channels, state);
+    // host route: channels are independent (the mode was chosen above for the whole batch, so every chunk runs the same
+    // kernels); the small state array rides along whole
+    const size_t row = n * sizeof(float);
+    return host_route(
+        x, row, bytes, y, row, channels, s,
+        [=](const void *din, void *dout, size_t u0, size_t count, void *daux) {
+            double *dstate = static_cast<double *>(daux);
+            return run(static_cast<const float *>(din), static_cast<float *>(dout), count,
+                       dstate ? dstate + u0 * 2 * static_cast<size_t>(poles) : nullptr);
+        },
+        state, state_bytes);
 }
 
 int dsp_gpu_iir_multi(const float *x, float *y, size_t channels, size_t n, const double *a, const double *b, int poles,

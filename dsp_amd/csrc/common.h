@@ -5,6 +5,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <functional>
 
 #include "../../include/dsp_gpu.h"
 
@@ -65,6 +66,27 @@ int allow_full_lds(const void *fn);
 void release_all_workspaces();
 bool iir_tables_in_use(int dev);
 void release_iir_tables(int dev);  // cached IIR scan tables of device `dev`, which must be current and idle (dsp_gpu_shutdown)
+
+// ---- the host-pointer route (host_path.hip) ------------------------------------------------------------------
+// A batch of `units` independent units (transforms / channels) living in host memory: unit u of the input starts at
+// in + u * in_unit (in_total bytes in all: the last one may be shorter than in_unit), unit u of the output at
+// out + u * out_unit.  launch(d_in, d_out, unit0, count) enqueues on the caller's stream the kernels for units
+// [unit0, unit0 + count), whose staged input / output start at d_in / d_out.
+// `aux` (may be null): a small host array read before and rewritten after the call as a whole (IIR state); its device
+// copy is handed to every launch as d_aux.
+struct HostJob {
+    const char *in;
+    size_t in_unit, in_total;
+    char *out;
+    size_t out_unit;
+    size_t units;
+    void *aux;
+    size_t aux_bytes;
+    std::function<int(const void *d_in, void *d_out, size_t unit0, size_t count, void *d_aux)> launch;
+};
+int run_host_job(const HostJob &job, hipStream_t s);  // returns when `out` is complete
+bool host_pipe_in_use(int dev);
+void release_host_pipes(int dev);
 
 // ---- kernel launchers (device pointers, asynchronous on `s`) --------------------------
 int launch_fft_batch(const float2 *in, float2 *out, int log2n, size_t batch, int direction, hipStream_t s);
