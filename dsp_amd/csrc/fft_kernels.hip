@@ -23,6 +23,7 @@
 //                              (ColumnPlan).  A transform of 2^13..2^16 points takes two such passes,
 //                              2^17..2^24 three, 2^25..2^30 four, all on one GPU.
 #include <algorithm>
+#include <cstdlib>
 #include <mutex>
 
 #include "common.h"
@@ -30,6 +31,8 @@
 
 namespace dspgpu {
 namespace {
+
+constexpr bool kRealHalf14Default = true;
 
 // REAL_IN: rows of real samples, zero padded (fft.h:65-74).  SHIFTED: dsp::shift fused (fft.h:85-94).
 template <int LOG2N, int SIGN, bool REAL_IN, bool SHIFTED>
@@ -149,7 +152,12 @@ __global__ __launch_bounds__(kThreads) void fft_lds_kernel(const void *__restric
 // (70 / 139 KB: two / one workgroup per CU), four radix passes, three exchanges.  With so few workgroups per CU
 // nothing else hides the loads, so the workgroups are persistent and fetch the next transform into registers while
 // the current one is transformed.  XCD x owns the contiguous range [x*chunk, (x+1)*chunk) of the batch.
-template <int LOG2N, int SIGN, bool REAL_IN, bool SHIFTED>
+// REAL_HALF: a real row of 2N samples rides an N-point complex transform (z[m] = x[2m] + i x[2m+1], which is just the
+// row read as complex values) and the 2N-bin spectrum the reference returns is unfolded from it in the same workgroup:
+// with E / O the transforms of the even / odd samples, Z[k] = E[k] + i O[k] and, x being real, conj Z[N-k] = E[k] - i O[k];
+// X[k] = E[k] + W_2N^k O[k], X[k+N] = E[k] - W_2N^k O[k].  Half the butterflies and half the LDS of the full-length
+// transform, and rows of 2^15 samples still take one trip through HBM (4 B read + 8 B written per sample).
+template <int LOG2N, int SIGN, bool REAL_IN, bool SHIFTED, bool REAL_HALF = false>
 __global__ __launch_bounds__((1 << LOG2N) / kPoints) void fft_big_kernel(const void *__restrict__ in_, c32 *__restrict__ out,
                                                                          size_t batch, size_t chunk, size_t n_in,
                                                                          size_t in_stride) {
@@ -162,7 +170,20 @@ __global__ __launch_bounds__((1 << LOG2N) / kPoints) void fft_big_kernel(const v
     size_t t = lo + (blockIdx.x >> 3);
     if (t >= hi) return;
     auto fetch = [&](c32 (&v)[kPoints], size_t row) {
-        if constexpr (REAL_IN) {  // rows of real samples, zero padded (fft.h:65-74)
+        if constexpr (REAL_HALF) {
+            const float *src = static_cast<const float *>(in_) + row * in_stride;
+            const bool pairs = (in_stride & 1) == 0 && (reinterpret_cast<uintptr_t>(in_) & 7) == 0;
+            if (pairs && n_in >= static_cast<size_t>(2 * N)) {  // no padding, 8-byte aligned rows: the row IS the complex input
+#pragma unroll
+                for (int m = 0; m < kPoints; ++m) v[m] = load_stream(reinterpret_cast<const c32 *>(src) + lt + T * m);
+            } else {
+#pragma unroll
+                for (int m = 0; m < kPoints; ++m) {
+                    const size_t i = 2 * static_cast<size_t>(lt + T * m);
+                    v[m] = mk(i < n_in ? src[i] : 0.0f, i + 1 < n_in ? src[i + 1] : 0.0f);
+                }
+            }
+        } else if constexpr (REAL_IN) {  // rows of real samples, zero padded (fft.h:65-74)
             const float *src = static_cast<const float *>(in_) + row * in_stride;
 #pragma unroll
             for (int m = 0; m < kPoints; ++m) {
@@ -184,6 +205,34 @@ __global__ __launch_bounds__((1 << LOG2N) / kPoints) void fft_big_kernel(const v
         if (t + per_xcd < hi) fetch(nxt, t + per_xcd);
         fft_passes<LOG2N, SIGN>(r, big_lds, lt, 0);
         __syncthreads();  // the last image has been read before the next transform's first exchange
+        if constexpr (REAL_HALF) {
+            // Z in natural order through the image once more: bin k needs its mirror N - k
+#pragma unroll
+            for (int m = 0; m < kPoints; ++m) big_lds[padded(lt + T * m)] = r[m];
+            __syncthreads();
+            // W_2N^k, k = lt + T m:  W^lt (W^T)^m -- two sincos and a product tree
+            const c32 w0 = unit_root<SIGN>(static_cast<unsigned>(lt), LOG2N + 1);
+            c32 pw[kPoints];
+            pw[1] = unit_root<SIGN>(static_cast<unsigned>(T), LOG2N + 1);
+#pragma unroll
+            for (int m = 2; m < kPoints; ++m) pw[m] = cmul(pw[m >> 1], pw[m - (m >> 1)]);
+            c32 *row = out + t * (2 * N);
+#pragma unroll
+            for (int m = 0; m < kPoints; ++m) {
+                const int k = lt + T * m;
+                const c32 zp = big_lds[padded((N - k) & (N - 1))];
+                const c32 zc = mk(zp.x, -zp.y);                       // conj Z[N - k] = E - i O
+                const c32 e = (r[m] + zc) * 0.5f;
+                const c32 d = (r[m] - zc) * 0.5f;                      // i O
+                const c32 o = mk(d.y, -d.x);                           // O = -i (i O)
+                const c32 wo = cmul(o, m == 0 ? w0 : cmul(w0, pw[m]));
+                // dsp::shift fused (fft.h:85-94): the halves of the 2N-bin row change places
+                store_stream(row + (SHIFTED ? k + N : k), e + wo);
+                store_stream(row + (SHIFTED ? k : k + N), e - wo);
+            }
+            __syncthreads();  // the image is the next transform's exchange buffer
+            continue;
+        }
 #pragma unroll
         for (int m = 0; m < kPoints; ++m) {
             int k = lt + T * m;
@@ -241,6 +290,12 @@ struct ColumnPlan {
     // first pass of a large real-input transform (dsp::fft, fft.h:57-83): `in` is really float rows of real_n_in
     // samples (row stride real_stride); element (a, l, b) = sample l*B + b of row a, zero beyond real_n_in
     size_t real_n_in = 0, real_stride = 0;
+    // Half-length form of a large real-input transform (see fft_big_kernel, REAL_HALF): the 2M real samples of a row ride
+    // an M-point complex transform.  real_pairs (first pass): element (a, l, b) = (x[2i], x[2i+1]), i = l*B + b.
+    // unfold (last pass, natural-order output Z[b + B k]): the workgroup takes C/2 columns and their mirrors B - b, so that
+    // every bin finds Z[M - k] in its own LDS image, and stores the 2M-bin spectrum X[k] = E + W_2M^k O, X[k + M] = E - W O
+    // (rows out_a apart); unfold == 2 swaps the two halves of the row (dsp::shift, fft.h:85-94).
+    int real_pairs = 0, unfold = 0;
 };
 
 template <int R, int NS, int LOG2L, int C>
@@ -276,12 +331,23 @@ __global__ __launch_bounds__(TH) void fft_column_kernel(const c32 *__restrict__ 
     const size_t tile = (ntile & 7) == 0 ? xcd_tile(blockIdx.x, chunkx) : blockIdx.x;  // tiles never straddle an `a` slab: B % C == 0
     const size_t tiles_per_a = columns_per_a / C;
     const size_t a = tile / tiles_per_a;
-    const size_t b = (tile % tiles_per_a) * C + c;
+    size_t b = (tile % tiles_per_a) * C + c;
+    if (plan.unfold) {  // C/2 columns j = 1, 2, ... and their mirrors B - j; the self-mirrored columns 0 and B/2 share "pair" 0
+        const size_t j = (tile % tiles_per_a) * (C / 2) + (c < C / 2 ? c : c - C / 2);
+        b = c < C / 2 ? j : (j == 0 ? plan.B / 2 : plan.B - j);
+    }
     const size_t in_lo = plan.in_lo ? plan.in_lo : plan.B;
     const c32 *src = in + a * (plan.in_a ? plan.in_a : L * plan.B) + b;
 
     c32 r[kPoints];
-    if (plan.real_stride) {
+    if (plan.real_stride && plan.real_pairs) {
+        const float *row = reinterpret_cast<const float *>(in) + a * plan.real_stride;
+#pragma unroll
+        for (int m = 0; m < kPoints; ++m) {
+            const size_t i = 2 * (static_cast<size_t>(lt + T * m) * plan.B + b);
+            r[m] = mk(i < plan.real_n_in ? row[i] : 0.0f, i + 1 < plan.real_n_in ? row[i + 1] : 0.0f);
+        }
+    } else if (plan.real_stride) {
         const float *row = reinterpret_cast<const float *>(in) + a * plan.real_stride;
 #pragma unroll
         for (int m = 0; m < kPoints; ++m) {
@@ -337,6 +403,43 @@ __global__ __launch_bounds__(TH) void fft_column_kernel(const c32 *__restrict__ 
         r[0] = cmul(r[0], w0);
 #pragma unroll
         for (int m = 1; m < kPoints; ++m) r[m] = cmul(r[m], cmul(w0, pw[m]));
+    }
+    if (plan.unfold) {
+        // Z[b + B k] of the tile's columns, as [column slot][k], so that bin k finds its mirror M - k = (B - b) + B (L - 1 - k)
+        // (column 0: B (L - k)) in the partner slot
+        __syncthreads();  // the last exchange's image has been read by everyone
+#pragma unroll
+        for (int m = 0; m < kPoints; ++m) lds[c * (L + 1) + lt + T * m] = r[m];
+        __syncthreads();
+        const size_t j = (tile % tiles_per_a) * (C / 2) + (c < C / 2 ? c : c - C / 2);
+        const int cp = j == 0 ? c : (c < C / 2 ? c + C / 2 : c - C / 2);
+        const size_t M = static_cast<size_t>(L) * plan.B;
+        int log2b = 0;
+        while ((static_cast<size_t>(1) << log2b) < plan.B) ++log2b;
+        // W_2M^{b + B k} = W_2M^b * W_2L^k, k = lt + T m: three roots and a product tree
+        const c32 wcol = LOG2L + log2b + 1 <= 24 ? unit_root<SIGN>(static_cast<unsigned>(b), LOG2L + log2b + 1)
+                                                 : unit_root_wide<SIGN>(b, LOG2L + log2b + 1);
+        const c32 w0 = cmul(wcol, unit_root<SIGN>(static_cast<unsigned>(lt), LOG2L + 1));
+        c32 pw[kPoints];
+        pw[1] = unit_root<SIGN>(static_cast<unsigned>(T), LOG2L + 1);
+#pragma unroll
+        for (int m = 2; m < kPoints; ++m) pw[m] = cmul(pw[m >> 1], pw[m - (m >> 1)]);
+        c32 *rowp = out + a * plan.out_a;
+        const size_t lo_off = plan.unfold == 2 ? M : 0, hi_off = plan.unfold == 2 ? 0 : M;
+#pragma unroll
+        for (int m = 0; m < kPoints; ++m) {
+            const int k = lt + T * m;
+            const int kp = b == 0 ? ((L - k) & (L - 1)) : L - 1 - k;
+            const c32 zp = lds[cp * (L + 1) + kp];
+            const c32 zc = mk(zp.x, -zp.y);             // conj Z[M - k] = E - i O
+            const c32 e = (r[m] + zc) * 0.5f;
+            const c32 d = (r[m] - zc) * 0.5f;            // i O
+            const c32 wo = cmul(mk(d.y, -d.x), m == 0 ? w0 : cmul(w0, pw[m]));
+            const size_t kk = b + plan.B * static_cast<size_t>(k);
+            store_stream(rowp + lo_off + kk, e + wo);
+            store_stream(rowp + hi_off + kk, e - wo);
+        }
+        return;
     }
     if (plan.s_k == 1 && plan.Bi == 1) {
         // transposed store (k contiguous per column): stage the tile as [column][k] so that a wave writes 512
@@ -471,9 +574,11 @@ int launch_column(int log2l, const c32 *in, c32 *out, const ColumnPlan &plan, si
 // passes ping-pong between `out` and one scratch buffer so that the input is never modified.
 // `fixed_scratch` != nullptr: the caller's buffer of at least batch * n points is the scratch (the allocation-free
 // entry point); otherwise the library's growing workspace.
+// real_half (real_in only; 0 off, 1 on, 2 on + dsp::shift): log2n is then the length of the COMPLEX transform the rows ride
+// (half their padded length) and the last pass unfolds the full spectrum, rows of 2^(log2n+1) bins.
 int launch_large(const c32 *in, c32 *out, int log2n, size_t batch, int direction, hipStream_t s,
                  const float *real_in = nullptr, size_t real_n_in = 0, size_t real_stride = 0,
-                 c32 *fixed_scratch = nullptr) {
+                 c32 *fixed_scratch = nullptr, int real_half = 0) {
     const size_t n = static_cast<size_t>(1) << log2n;
     const int steps = log2n <= 16 ? 2 : (log2n <= 24 ? 3 : 4);
     int lg[4] = {0, 0, 0, 0};
@@ -502,6 +607,11 @@ int launch_large(const c32 *in, c32 *out, int log2n, size_t batch, int direction
         if (i == 0 && real_in) {  // the real -> complex packing rides the first pass's loads
             p.real_n_in = real_n_in;
             p.real_stride = real_stride;
+            p.real_pairs = real_half ? 1 : 0;
+        }
+        if (real_half && i + 1 == steps) {
+            p.unfold = real_half;
+            p.out_a = 2 * n;
         }
         if (int rc = launch_column(lg[i], src, dst, p, batch, direction, s)) return rc;
         src = dst;
@@ -514,14 +624,14 @@ int launch_large(const c32 *in, c32 *out, int log2n, size_t batch, int direction
 }  // namespace
 
 namespace {
-template <int LOG2N, bool REAL_IN, bool SHIFTED>
+template <int LOG2N, bool REAL_IN, bool SHIFTED, bool REAL_HALF = false>
 int launch_big(const void *in, c32 *out, size_t batch, size_t n_in, size_t in_stride, int direction, hipStream_t s) {
     constexpr int N = 1 << LOG2N;
     const size_t lds_bytes = static_cast<size_t>(N + N / 16) * sizeof(c32);
     const size_t chunk = (batch + 7) / 8;
     const size_t per_xcd = std::min<size_t>(chunk, 32 * (LOG2N == 13 ? 2 : 1));  // resident workgroups per XCD
-    auto kf = fft_big_kernel<LOG2N, +1, REAL_IN, SHIFTED>;
-    auto ki = fft_big_kernel<LOG2N, -1, REAL_IN, SHIFTED>;
+    auto kf = fft_big_kernel<LOG2N, +1, REAL_IN, SHIFTED, REAL_HALF>;
+    auto ki = fft_big_kernel<LOG2N, -1, REAL_IN, SHIFTED, REAL_HALF>;
     auto kern = direction == DSP_GPU_FORWARD ? kf : ki;
     if (int rc = allow_full_lds(reinterpret_cast<const void *>(kern))) return rc;
     hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(8 * per_xcd)), dim3(N / kPoints), lds_bytes, s, in, out, batch, chunk,
@@ -623,6 +733,17 @@ int launch_fft_rows_exchange(const float2 *in_f2, float2 *out_f2, int log2n2, si
     return launch_column(lb, scratch, out, p2, rows, direction, s);
 }
 
+// DSP_GPU_REAL_HALF_14=0/1 (A/B): whether rows of 2^14 real samples take the half-length form too
+static bool real_half_14() {
+    const char *e = getenv("DSP_GPU_REAL_HALF_14");
+    return e ? e[0] == '1' : kRealHalf14Default;
+}
+
+static bool real_half_large() {  // DSP_GPU_REAL_HALF_LARGE=0: the full-length route (A/B, tests of both)
+    const char *e = getenv("DSP_GPU_REAL_HALF_LARGE");
+    return !e || e[0] != '0';
+}
+
 int launch_fft_real_batch(const float *in, size_t n_in, size_t in_stride, float2 *out_f2, int log2n, size_t batch,
                           int direction, int shifted, hipStream_t s) {
     c32 *out = reinterpret_cast<c32 *>(out_f2);
@@ -631,6 +752,12 @@ int launch_fft_real_batch(const float *in, size_t n_in, size_t in_stride, float2
         if (shifted) return dispatch_small<true, true>(log2n, in, out, batch, n_in, in_stride, direction, s);
         return dispatch_small<true, false>(log2n, in, out, batch, n_in, in_stride, direction, s);
     }
+    if (log2n == 15)  // 2^15 real samples ride one 2^14-point complex transform: still a single HBM pass
+        return shifted ? launch_big<14, true, true, true>(in, out, batch, n_in, in_stride, direction, s)
+                       : launch_big<14, true, false, true>(in, out, batch, n_in, in_stride, direction, s);
+    if (log2n == 14 && real_half_14())
+        return shifted ? launch_big<13, true, true, true>(in, out, batch, n_in, in_stride, direction, s)
+                       : launch_big<13, true, false, true>(in, out, batch, n_in, in_stride, direction, s);
     if (log2n == 13 || log2n == 14) {  // one HBM pass
         if (log2n == 13)
             return shifted ? launch_big<13, true, true>(in, out, batch, n_in, in_stride, direction, s)
@@ -638,6 +765,8 @@ int launch_fft_real_batch(const float *in, size_t n_in, size_t in_stride, float2
         return shifted ? launch_big<14, true, true>(in, out, batch, n_in, in_stride, direction, s)
                        : launch_big<14, true, false>(in, out, batch, n_in, in_stride, direction, s);
     }
+    if (real_half_large())  // the rows ride a half-length complex transform; the last pass unfolds (and shifts) the spectrum
+        return launch_large(nullptr, out, log2n - 1, batch, direction, s, in, n_in, in_stride, nullptr, shifted ? 2 : 1);
     const size_t n = static_cast<size_t>(1) << log2n;
     const size_t total = batch * n;
     const unsigned grid = static_cast<unsigned>(std::min<size_t>((total + kThreads - 1) / kThreads, 2048 * 8));

@@ -100,7 +100,9 @@ def test_real_wrapper_golden(ops, dev, golden, tag, nf):
 
 
 @pytest.mark.parametrize("n_in,nf,batch", [(100, 128, 4), (300, 300, 3), (4096, 4096, 2), (5000, 4096, 2), (3, 2, 5),
-                                           (20000, 20000, 2), (70000, 1 << 17, 1), (6000, 8192, 3), (9000, 16384, 2), (16384, 16384, 70)])
+                                           (20000, 20000, 2), (70000, 1 << 17, 1), (6000, 8192, 3), (9000, 16384, 2), (16384, 16384, 70),
+                                           (32768, 32768, 9), (32767, 32768, 2), (65536, 65536, 3), (65535, 65536, 2), (1, 65536, 1),
+                                           (100001, 1 << 17, 2), (1 << 18, 1 << 18, 2), (300000, 1 << 19, 1), (1 << 20, 1 << 20, 1)])
 def test_real_wrapper_oracle(ops, dev, orc, n_in, nf, batch):
     import torch
     rng = np.random.default_rng(n_in + nf)
@@ -237,3 +239,27 @@ def test_single_pass_8k_16k(ops, dev, orc, log2n, batch):
     buf = x.clone()
     ops.fft0(buf, out=buf)
     assert torch.equal(buf, X)
+
+
+@pytest.mark.parametrize("log2n", [15, 16, 18, 21, 25])
+def test_real_half_length_route_equals_full_length(ops, dev, log2n, monkeypatch):
+    """Rows of 2^15 samples and more ride a half-length complex transform (N/2 trick, spectrum unfolded in the last
+    pass); the full-length route stays selectable: both must agree, with and without dsp::shift."""
+    import torch
+    g = torch.Generator(device=dev).manual_seed(log2n)
+    n = 1 << log2n
+    batch = 3 if log2n <= 18 else 1
+    x = torch.randn(batch, n - 5, device=dev, generator=g)  # zero padded by 5 samples
+    got = {}
+    for half in ("1", "0"):
+        monkeypatch.setenv("DSP_GPU_REAL_HALF_LARGE", half)
+        monkeypatch.setenv("DSP_GPU_REAL_HALF_14", half)
+        got[half] = (ops.fft(x, n), ops.fft(x, n, inverse=True, shift=True))
+    if log2n >= 16:
+        for a, b in zip(got["1"], got["0"]):
+            den = torch.linalg.vector_norm(b.view(torch.float32).double())
+            assert float(torch.linalg.vector_norm((a - b).view(torch.float32).double()) / den) <= budget(log2n)
+    # Hermitian symmetry of a real row's spectrum and the DC bin
+    X = got["1"][0]
+    assert float((X[:, 1:] - X[:, 1:].flip(1).conj()).abs().max()) <= 1e-3 * float(X.abs().max())
+    assert float((X[:, 0].real - x.double().sum(1).float()).abs().max()) <= 2e-3 * float(x.abs().sum(1).max()) ** 0.5 + 1e-1
