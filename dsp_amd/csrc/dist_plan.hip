@@ -169,35 +169,82 @@ int dsp_gpu_fft_dist_phase(dsp_gpu_fft_dist_plan *plan, int phase, const void *i
                      static_cast<hipStream_t>(stream));
 }
 
-int dsp_gpu_fft_dist(dsp_gpu_fft_dist_plan *plan, const void *in, void *out, int direction, void *stream) {
+int dsp_gpu_fft_dist_ex(dsp_gpu_fft_dist_plan *plan, const void *in, void *out, int direction, int flags, void *stream) {
     if (!plan || !in || !out || in == out) return fail(DSP_GPU_EINVAL, "dsp_gpu_fft_dist: null plan or null / aliased buffer");
     if (int rc = check_direction("dsp_gpu_fft_dist", direction)) return rc;
+    if (flags & ~DSP_GPU_DIST_TRANSPOSED_OUT) return fail(DSP_GPU_EINVAL, "dsp_gpu_fft_dist: flags %d", flags);
     if (plan->world > 1 && !plan->exchange) return fail(DSP_GPU_EINVAL, "dsp_gpu_fft_dist: the plan has no exchange (use the phase calls)");
     float2 *w = nullptr;
     if (int rc = work_buffer(plan, &w)) return rc;
     auto s = static_cast<hipStream_t>(stream);
     float2 *o = static_cast<float2 *>(out);
     const size_t block_bytes = plan->local / plan->world * sizeof(float2);
-    const float2 *cur = static_cast<const float2 *>(in);
-    // hops alternate between `out` and the work buffer so that the last one lands in `out`:
-    // seven with exchanges (in->out->w->out->w->out->w->out), four without (in->w->out->w->out).
     const bool exchanging = plan->exchange != nullptr;  // at world 1 a given exchange still runs (a self copy)
-    float2 *next = exchanging ? o : w;
-    for (int phase = 0; phase < 4; ++phase) {
-        // phase 2's three-pass fallback needs a spare buffer: its input, which its first hop has consumed by then
-        // (never the caller's `in`: that is phase 0's input only)
-        float2 *tmp = phase == 2 ? const_cast<float2 *>(cur) : nullptr;
-        if (int rc = run_phase(plan, phase, cur, next, tmp, direction, s)) return rc;
+    const bool transposed = (flags & DSP_GPU_DIST_TRANSPOSED_OUT) != 0;
+    // The steps: local phases with an exchange behind each but the last.  Without an exchange (world 1) the pack of
+    // phase 0 is a plain copy and is left out.  TRANSPOSED_OUT ends after the transform over n2: no third exchange, no
+    // final transpose -- the rank keeps X[k1 + N1 k2] for ITS rows k1 = rank * N1/G + r as out[r][k2].
+    enum { PACK, FFT_N1, FFT_N2, NATURAL, ROWS_UNPACK, ROWS_FFT, EXCHANGE };
+    int steps[8], nsteps = 0;
+    if (exchanging) steps[nsteps++] = PACK, steps[nsteps++] = EXCHANGE;
+    steps[nsteps++] = FFT_N1;
+    if (exchanging) steps[nsteps++] = EXCHANGE;
+    if (transposed) {
+        steps[nsteps++] = ROWS_UNPACK;
+        steps[nsteps++] = ROWS_FFT;  // in place when its input is `out`, else a hop
+    } else {
+        steps[nsteps++] = FFT_N2;
+        if (exchanging) steps[nsteps++] = EXCHANGE;
+        steps[nsteps++] = NATURAL;
+    }
+    // hops alternate between `out` and the work buffer; the first destination is chosen so that the last one is `out`
+    // (`in` is never written).  ROWS_FFT hops only if it does not already sit in `out`.
+    int hops = 0;
+    for (int i = 0; i < nsteps; ++i) hops += steps[i] != ROWS_FFT;
+    // after the hops before ROWS_FFT the data is in `out` iff their number has the parity that starts in `out`
+    const bool start_in_out = transposed ? true : (hops % 2 == 1);  // transposed: ROWS_UNPACK must land in w or o, see below
+    const float2 *cur = static_cast<const float2 *>(in);
+    float2 *next = nullptr;
+    if (transposed) {
+        // hops before ROWS_FFT (incl. ROWS_UNPACK): if even the unpack lands in `w` and ROWS_FFT hops w -> out; if odd it
+        // lands in `out` and ROWS_FFT runs in place.  Either first destination works; start in `out`.
+        next = o;
+    } else {
+        next = start_in_out ? o : w;
+    }
+    const size_t G = plan->world, R = plan->rows, C = plan->cols;
+    for (int i = 0; i < nsteps; ++i) {
+        int rc = DSP_GPU_OK;
+        switch (steps[i]) {
+        case PACK: rc = run_phase(plan, 0, cur, next, nullptr, direction, s); break;
+        case FFT_N1: rc = run_phase(plan, 1, cur, next, nullptr, direction, s); break;
+        case FFT_N2:
+            // phase 2's three-pass fallback needs a spare buffer: its input, which its first hop has consumed by then
+            // (never the caller's `in`: a phase-1 result precedes it)
+            rc = run_phase(plan, 2, cur, next, const_cast<float2 *>(cur), direction, s);
+            break;
+        case NATURAL: rc = run_phase(plan, 3, cur, next, nullptr, direction, s); break;
+        case ROWS_UNPACK:  // [G][R][C] -> [R][N2], times W_N^{k1 n2}
+            rc = launch_swap_axes(cur, next, G, R, C, plan->log2n, static_cast<unsigned long long>(plan->rank) * R, direction, s);
+            break;
+        case ROWS_FFT:
+            rc = launch_fft_batch(cur, o, plan->log2n2, R, direction, s);  // cur == o: in place
+            next = o;
+            break;
+        case EXCHANGE:
+            rc = plan->exchange(plan->user, cur, next, block_bytes, plan->world, stream);
+            if (rc > 0) rc = fail(DSP_GPU_EHIP, "dsp_gpu_fft_dist: the exchange callback returned %d", rc);
+            break;
+        }
+        if (rc) return rc;
         cur = next;
         next = cur == o ? w : o;
-        if (phase < 3 && exchanging) {
-            if (int rc = plan->exchange(plan->user, cur, next, block_bytes, plan->world, stream))
-                return rc < 0 ? rc : fail(DSP_GPU_EHIP, "dsp_gpu_fft_dist: the exchange callback returned %d", rc);
-            cur = next;
-            next = cur == o ? w : o;
-        }
     }
     return DSP_GPU_OK;
+}
+
+int dsp_gpu_fft_dist(dsp_gpu_fft_dist_plan *plan, const void *in, void *out, int direction, void *stream) {
+    return dsp_gpu_fft_dist_ex(plan, in, out, direction, 0, stream);
 }
 
 int dsp_gpu_fft_dist_plan_destroy(dsp_gpu_fft_dist_plan *plan) {

@@ -139,12 +139,14 @@ class NativePlan:
                                                                int(inverse), self._stream(t)))
         return out
 
-    def run(self, t, inverse: bool = False, out=None):
-        """The whole transform through dsp_gpu_fft_dist (exchange callback or RCCL communicator of the plan)."""
+    def run(self, t, inverse: bool = False, out=None, transposed: bool = False):
+        """The whole transform through dsp_gpu_fft_dist_ex (exchange callback or RCCL communicator of the plan).
+        transposed: keep the spectrum as out[r][k2] = X[(rank*N1/G + r) + N1*k2] -- one exchange and one pass fewer."""
         if t.numel() != self.local_points:
             raise ValueError("x_local must hold N / world points")
         out = self.torch.empty_like(t) if out is None else out
-        rc = self.capi.lib().dsp_gpu_fft_dist(self._handle, t.data_ptr(), out.data_ptr(), int(inverse), self._stream(t))
+        rc = self.capi.lib().dsp_gpu_fft_dist_ex(self._handle, t.data_ptr(), out.data_ptr(), int(inverse),
+                                                 self.capi.DIST_TRANSPOSED_OUT if transposed else 0, self._stream(t))
         err, self._error = getattr(self, "_error", None), None
         if err is not None:
             raise err
@@ -257,8 +259,11 @@ def fft_dist(x_local, log2n: int, inverse: bool = False, group=None, ops=None):
     plan = make_plan(log2n, world)
     if x_local.numel() != (1 << log2n) // world:
         raise ValueError("x_local must hold N / world points")
-    steps = phases(plan, rank, ops, inverse) if ops is not None else native_phases(log2n, rank, world, inverse)
     t = x_local.reshape(-1).contiguous()
+    if ops is None and world == 1:  # one rank: the library's whole-transform call (no exchange, no pack)
+        native_phases(log2n, 0, 1, inverse)
+        return _plans[(log2n, 0, 1)].run(t, inverse)
+    steps = phases(plan, rank, ops, inverse) if ops is not None else native_phases(log2n, rank, world, inverse)
     for i, step in enumerate(steps):
         t = step(t)
         if i + 1 < len(steps) and world > 1:

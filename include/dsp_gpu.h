@@ -238,6 +238,15 @@ int dsp_gpu_fft_dist_plan_create(dsp_gpu_fft_dist_plan **plan, int log2n, int ra
 int dsp_gpu_fft_dist_plan_create_rccl(dsp_gpu_fft_dist_plan **plan, int log2n, int rank, int world, void *nccl_comm);
 size_t dsp_gpu_fft_dist_local_points(const dsp_gpu_fft_dist_plan *plan);
 int dsp_gpu_fft_dist(dsp_gpu_fft_dist_plan *plan, const void *in, void *out, int direction, void *stream);
+/*
+ * The same with options.  DSP_GPU_DIST_TRANSPOSED_OUT leaves the spectrum where the transform over n2 produces it: rank g
+ * receives out[r][k2] = X[(g*N1/G + r) + N1*k2] (N1/G rows of N2 bins) instead of its natural-order slice, which
+ * saves the third all-to-all exchange and the final transpose -- the step SURVEY.md 8(e) marks as skippable when a
+ * transposed result will do (a spectrum that is only multiplied pointwise and transformed back, a power spectrum ...).
+ * A plan without an exchange (one rank) also skips the pack in front of the first exchange, a plain copy there.
+ */
+#define DSP_GPU_DIST_TRANSPOSED_OUT 1
+int dsp_gpu_fft_dist_ex(dsp_gpu_fft_dist_plan *plan, const void *in, void *out, int direction, int flags, void *stream);
 int dsp_gpu_fft_dist_phase(dsp_gpu_fft_dist_plan *plan, int phase, const void *in, void *out, int direction,
                            void *stream);
 int dsp_gpu_fft_dist_plan_destroy(dsp_gpu_fft_dist_plan *plan);

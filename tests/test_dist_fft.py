@@ -266,8 +266,29 @@ def test_native_plan_whole_transform_world_of_one(dev, log2n):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("log2n", [16, 19, 24])
+def test_native_plan_transposed_out_world_of_one(dev, log2n):
+    """DSP_GPU_DIST_TRANSPOSED_OUT on one rank: out[r][k2] = X[r + N1 k2]."""
+    import torch
+    from dsp_amd import dist_fft, ops
+    g = torch.Generator(device=dev).manual_seed(log2n)
+    x = torch.view_as_complex(torch.randn(1 << log2n, 2, device=dev, generator=g))
+    n1 = 1 << ((log2n + 1) // 2)
+    plan = dist_fft.NativePlan(log2n, 0, 1)
+    try:
+        for inverse in (False, True):
+            got = plan.run(x, inverse, transposed=True).reshape(n1, -1)
+            want = ops.fft0(x[None], inverse=inverse)[0].reshape(-1, n1).T  # X[k1 + N1 k2] -> [k1][k2]
+            err = torch.linalg.vector_norm((got - want).contiguous().view(torch.float32).double()) / torch.linalg.vector_norm(want.contiguous().view(torch.float32).double())
+            assert float(err) <= 1e-5 * log2n
+    finally:
+        plan.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("transposed", [False, True])
 @pytest.mark.parametrize("log2n,world", [(16, 2), (20, 4), (18, 8), (22, 8)])
-def test_native_plan_with_exchange_callback(orc, dev, log2n, world):
+def test_native_plan_with_exchange_callback(orc, dev, log2n, world, transposed):
     """dsp_gpu_fft_dist with a caller-supplied exchange: `world` host threads, one plan each, on one GPU and one
     stream.  The callback trades blocks with device copies.  A baton keeps one thread at a time inside the
     library (calls that use the library's scratch must not overlap on a device)."""
@@ -320,8 +341,9 @@ def test_native_plan_with_exchange_callback(orc, dev, log2n, world):
             torch.cuda.set_device(dev)
             with baton:
                 try:
-                    plans[r].capi.check(plans[r].capi.lib().dsp_gpu_fft_dist(plans[r]._handle, parts[r].data_ptr(),
-                                                                            outs[r].data_ptr(), int(inverse), stream))
+                    plans[r].capi.check(plans[r].capi.lib().dsp_gpu_fft_dist_ex(plans[r]._handle, parts[r].data_ptr(),
+                                                                               outs[r].data_ptr(), int(inverse),
+                                                                               1 if transposed else 0, stream))
                 except Exception as e:  # noqa: BLE001
                     errors.append(e)
                     barrier.abort()
@@ -333,9 +355,13 @@ def test_native_plan_with_exchange_callback(orc, dev, log2n, world):
             t.join(timeout=120)
         torch.cuda.synchronize()
         assert not errors, errors
-        assert calls == [3] * world
+        assert calls == [2 if transposed else 3] * world
         got = torch.cat(outs).cpu().numpy()
-        assert rel_l2(got, orc.fft0(x.astype(np.complex128), inverse)) <= 1e-5 * log2n
+        want = orc.fft0(x.astype(np.complex128), inverse)
+        if transposed:  # the ranks' row blocks stacked: [k1][k2] = X[k1 + N1 k2]
+            n1 = 1 << ((log2n + 1) // 2)
+            want = want.reshape(-1, n1).T.reshape(-1)
+        assert rel_l2(got, want) <= 1e-5 * log2n
         for p in plans:
             p.close()
 
