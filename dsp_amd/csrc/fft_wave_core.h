@@ -97,18 +97,26 @@ struct Dft<64, SIGN> {
 // imaginary parts cross one after the other -- half the LDS, twice the dependent phases.
 constexpr int kWaveLdsWideBytes = 64 * kWaveRow * 8;
 
-template <bool WIDE>
+// WRITTEN (WIDE only): the caller has already stored r[j] at row j, column `lane` of the image
+template <bool WIDE, bool WRITTEN = false>
 DSP_DEV void wave_transpose(c32 (&r)[kWavePoints], float *img, int lane) {
     if constexpr (WIDE) {
         c32 *im2 = reinterpret_cast<c32 *>(img);
-        c32 *wr = im2 + lane;
         const c32 *rd = im2 + lane * kWaveRow;
+        if constexpr (!WRITTEN) {
+            c32 *wr = im2 + lane;
 #pragma unroll
-        for (int j = 0; j < kWavePoints; ++j) wr[j * kWaveRow] = r[j];
+            for (int j = 0; j < kWavePoints; ++j) wr[j * kWaveRow] = r[j];
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // in the order the next pass consumes them (its first 16-point sub-transform takes elements 0, 4, 8, ...), so that
+        // it can start while the rest are still on their way
 #pragma unroll
-        for (int j = 0; j < kWavePoints; ++j) r[j] = rd[j];
+        for (int n2 = 0; n2 < 4; ++n2) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) r[4 * i + n2] = rd[4 * i + n2];
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         return;
@@ -163,6 +171,8 @@ DSP_DEV void fft4096_wave(c32 (&r)[kWavePoints], float *img, int lane, Hook hook
         pa[1] = cmul(pb[4], pb[4]);
 #pragma unroll
         for (int t = 2; t < 8; ++t) pa[t] = cmul(pa[t >> 1], pa[t - (t >> 1)]);
+        c32 *wr = reinterpret_cast<c32 *>(img) + lane;  // WIDE: every point leaves for the transpose image as soon as it is ready
+        if constexpr (WIDE) wr[0] = r[0];
 #pragma unroll
         for (int a = 0; a < 8; ++a) {
 #pragma unroll
@@ -170,10 +180,11 @@ DSP_DEV void fft4096_wave(c32 (&r)[kWavePoints], float *img, int lane, Hook hook
                 if (a == 0 && b == 0) continue;
                 const c32 tw = a == 0 ? pb[b] : (b == 0 ? pa[a] : cmul(pa[a], pb[b]));
                 r[8 * a + b] = cmul(r[8 * a + b], tw);
+                if constexpr (WIDE) wr[(8 * a + b) * kWaveRow] = r[8 * a + b];
             }
         }
     }
-    wave_transpose<WIDE>(r, img, lane);
+    wave_transpose<WIDE, WIDE>(r, img, lane);
     Dft<64, SIGN>::run(r, [&](int i) { hook(8 + i); });
 }
 
