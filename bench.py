@@ -42,6 +42,8 @@ def parse():
                     help="weak: every GPU gets the full per-GPU batch; strong: the one-GPU batch is channel-sharded")
     ap.add_argument("--dist-exchange", default="torch", choices=["torch", "rccl"],
                     help="fft_dist only: all_to_all_single between the plan's phases, or dsp_gpu_fft_dist's own RCCL exchange")
+    ap.add_argument("--dist-serial", action="store_true",
+                    help="fft_dist with --dist-exchange rccl: the unpipelined schedule (A/B partner of the default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true",
                     help="default fft run only: skip the FIR / IIR / moving-average workloads reported under `secondary`")
@@ -142,7 +144,7 @@ def make_iir(torch, dev, ops, rank, mode):
     return step, channels * n, meta
 
 
-def make_fft_dist(torch, dev, world, rank, exchange):
+def make_fft_dist(torch, dev, world, rank, exchange, serial=False):
     """C5: ONE transform of world * 2^27 points (2^30 on 8 GPUs), six-step with all-to-all over xGMI."""
     from dsp_amd import dist_fft
     log2n = 27 + (world.bit_length() - 1)
@@ -156,7 +158,7 @@ def make_fft_dist(torch, dev, world, rank, exchange):
         y = torch.empty_like(x)
 
         def step():
-            plan.run(x, False, out=y)
+            plan.run(x, False, out=y, serial=serial)
     else:
 
         def step():  # the library's plan handle runs the local phases; torch.distributed (RCCL) the exchanges
@@ -166,8 +168,10 @@ def make_fft_dist(torch, dev, world, rank, exchange):
                 alg_per_unit=48.0, alg_unit="bytes/sample (3 local passes x 16 B; the exchanges ride xGMI)",
                 kernel="fft_column_kernel + fft_lds_kernel + swap_axes_kernel + transpose_blocks_kernel",
                 config={"workload": f"C5: one 2^{log2n}-point complex fp32 FFT, six-step, {world} GPU(s), 2^27 points per GPU",
-                        "log2n": log2n, "exchange": "3 x grouped ncclSend/ncclRecv inside dsp_gpu_fft_dist" if exchange == "rccl"
-                        else "3 x all_to_all_single (RCCL)"})
+                        "log2n": log2n,
+                        "exchange": (f"{plan.exchanges(serial=serial)} x grouped ncclSend/ncclRecv inside dsp_gpu_fft_dist"
+                                     f" ({'serial' if serial or plan.exchanges() == 3 else 'pipelined'} schedule)")
+                        if exchange == "rccl" else "3 x all_to_all_single (RCCL)"})
     return step, per_rank, meta
 
 
@@ -282,7 +286,7 @@ def main():
     def measure(workload, steps, warmup):
         """Warm up, then time exactly `steps` passes of one workload between barriers; returns the rank-0 record parts."""
         if workload == "fft_dist":
-            step, units, meta = make_fft_dist(torch, dev, world, rank, args.dist_exchange)
+            step, units, meta = make_fft_dist(torch, dev, world, rank, args.dist_exchange, args.dist_serial)
         elif workload == "fft":
             step, units, meta = make_fft(torch, dev, ops, rank)
         elif workload in ("fir_direct", "fir_direct_valu", "fir_os"):

@@ -18,6 +18,7 @@ MEM_HOST, MEM_DEVICE = 0, 1
 CONV_AUTO, CONV_DIRECT, CONV_OVERLAP_SAVE, CONV_DIRECT_VALU = 0, 1, 2, 3
 IIR_AUTO, IIR_BATCH, IIR_SCAN = 0, 1, 2
 DIST_TRANSPOSED_OUT = 1
+DIST_SERIAL = 2
 
 # every symbol include/dsp_gpu.h declares (tests check the library exports all of them)
 EXPORTS = (
@@ -43,6 +44,7 @@ EXPORTS = (
     "dsp_gpu_fft_dist_local_points",
     "dsp_gpu_fft_dist",
     "dsp_gpu_fft_dist_ex",
+    "dsp_gpu_fft_dist_exchanges",
     "dsp_gpu_fft_dist_phase",
     "dsp_gpu_fft_dist_plan_destroy",
 )
@@ -96,6 +98,8 @@ def lib() -> C.CDLL:
         L.dsp_gpu_fft_dist.argtypes = [vp, vp, vp, i, vp]
         L.dsp_gpu_fft_dist_ex.argtypes = [vp, vp, vp, i, i, vp]
         L.dsp_gpu_fft_dist_ex.restype = i
+        L.dsp_gpu_fft_dist_exchanges.argtypes = [vp, i]
+        L.dsp_gpu_fft_dist_exchanges.restype = i
         L.dsp_gpu_fft_dist_phase.argtypes = [vp, i, vp, vp, i, vp]
         L.dsp_gpu_fft_dist_plan_destroy.argtypes = [vp]
         for name in ("dsp_gpu_fft_dist_plan_create", "dsp_gpu_fft_dist_plan_create_rccl", "dsp_gpu_fft_dist",

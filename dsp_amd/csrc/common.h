@@ -100,6 +100,21 @@ int launch_fft_rows_exchange(const float2 *in, float2 *out, int log2n2, size_t r
 int launch_swap_axes(const float2 *in, float2 *out, size_t a, size_t b, size_t c, int tw_log2,
                      unsigned long long row0, int direction, hipStream_t s);
 int launch_transpose_blocks(const float2 *in, float2 *out, size_t blocks, size_t rows, size_t cols, hipStream_t s);
+// Chunk-wise forms for the pipelined distributed transform (dist_plan.hip):
+//   swap_axes_window       as swap_axes, but the innermost rows are windows of `c` elements in rows in_row / out_row long
+//                          (the pointers aim at the window); twiddle column of (a, ., c) = a*tw_c + tw_c0 + c
+//   transpose_blocks_into  out[col][blk][row_off + row], output rows out_rows long
+//   fft_rows_exchange_chunk  rows [row_off, row_off + rows) of the middle phase; `in` = [chunks][world][rows_total][C/chunks]
+//                          (column chunk i of every sender's block), out = [world][rows][C]
+int launch_swap_axes_window(const float2 *in, float2 *out, size_t a, size_t b, size_t c, size_t in_row, size_t out_row,
+                            int tw_log2, unsigned long long row0, size_t tw_c, size_t tw_c0, int direction, hipStream_t s);
+int launch_transpose_blocks_into(const float2 *in, float2 *out, size_t blocks, size_t rows, size_t cols, size_t out_rows,
+                                 size_t row_off, hipStream_t s);
+int launch_fft_rows_exchange_chunk(const float2 *in, float2 *out, int log2n2, size_t rows, size_t world, int tw_log2n,
+                                   unsigned long long row0, int direction, hipStream_t s, size_t chunks, size_t rows_total,
+                                   size_t row_off);
+bool fft_rows_exchange_covers(int log2n2, size_t world, size_t chunks);  // shapes the fused middle phase takes
+bool fft_columns_tiled(int log2n, size_t cols);                           // column passes (true) or the transpose route
 int launch_fir_direct(const float *x, float *y, size_t channels, size_t n, const float *d_taps,
                       int ntaps, const float *hist, int zero_head, hipStream_t s);
 int launch_fir_direct_valu(const float *x, float *y, size_t channels, size_t n, const float *d_taps, int ntaps,

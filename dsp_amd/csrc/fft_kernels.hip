@@ -280,8 +280,10 @@ struct ColumnPlan {
     // phase of the distributed transform, where the row axis is cut into per-rank blocks on both sides:
     size_t in_a = 0;      // input stride of a                                   (default L*B)
     size_t in_lo = 0;     // input stride of l & (2^in_split - 1)                  (default B)
-    size_t in_hi = 0;     // input stride of l >> in_split                       (0: l is not split)
+    size_t in_hi = 0;     // input stride of l >> (in_split + in_mid_bits)       (0: l is not split)
     int in_split = 0;
+    size_t in_mid = 0;    // input stride of the in_mid_bits bits of l above in_split (pipelined exchange: the column chunk)
+    int in_mid_bits = 0;
     int in_tw_log2 = 0;   // input element (a, l, b) is first multiplied by W^{(in_tw_row0 + a) * (l*B + b)}
     unsigned long long in_tw_row0 = 0;
     size_t out_a = 0;     // output stride of a                                  (default L*B)
@@ -353,6 +355,14 @@ __global__ __launch_bounds__(TH) void fft_column_kernel(const c32 *__restrict__ 
         for (int m = 0; m < kPoints; ++m) {
             const size_t i = static_cast<size_t>(lt + T * m) * plan.B + b;
             r[m] = mk(i < plan.real_n_in ? row[i] : 0.0f, 0.0f);
+        }
+    } else if (plan.in_hi && plan.in_mid_bits) {
+        const unsigned mask = (1u << plan.in_split) - 1u, mmask = (1u << plan.in_mid_bits) - 1u;
+#pragma unroll
+        for (int m = 0; m < kPoints; ++m) {
+            const unsigned l = lt + T * m;
+            r[m] = load_stream(src + static_cast<size_t>(l >> (plan.in_split + plan.in_mid_bits)) * plan.in_hi +
+                               static_cast<size_t>((l >> plan.in_split) & mmask) * plan.in_mid + static_cast<size_t>(l & mask) * in_lo);
         }
     } else if (plan.in_hi) {
         const unsigned mask = (1u << plan.in_split) - 1u;
@@ -663,10 +673,7 @@ int launch_fft_columns(const float2 *in_f2, float2 *out_f2, int log2n, size_t co
         // A column pass of length L moves 4096 / L adjacent columns per workgroup.  Narrower matrices (small transforms
         // spread over many ranks: 2^10 points on one rank give 32 columns against a tile of 128) take the general route:
         // transpose, transform the rows, transpose back.
-        const int la = log2n <= 8 ? log2n : (log2n + 1) / 2, lb = log2n <= 8 ? 0 : log2n - la;
-        const size_t na = static_cast<size_t>(1) << la, nb = static_cast<size_t>(1) << lb;
-        const bool fits = (nb * cols) % (kTile >> la) == 0 && (lb == 0 || (na * cols) % (kTile >> lb) == 0);
-        if (!fits) {
+        if (!fft_columns_tiled(log2n, cols)) {
             const size_t n = static_cast<size_t>(1) << log2n;
             void *tv = nullptr;
             if (int rc = workspace(WS_SCRATCH_B, n * cols * sizeof(c32), &tv)) return rc;
@@ -699,38 +706,75 @@ int launch_fft_columns(const float2 *in_f2, float2 *out_f2, int log2n, size_t co
 // N2 = G*C = N2a*N2b.  Pass 1 reads straight out of the received blocks (row axis split per rank), applies the
 // inter-step twiddle on load, transforms over n2a and stores [r][n2b][k2a]; pass 2 transforms over n2b and
 // stores straight into the blocks to send.
-int launch_fft_rows_exchange(const float2 *in_f2, float2 *out_f2, int log2n2, size_t rows, size_t world, int tw_log2n,
-                             unsigned long long row0, int direction, hipStream_t s) {
+namespace {
+struct RowsExchangeShape {
+    int la, lb;
+    size_t na, nb, C, cols1, cols2;
+    bool ok;
+};
+RowsExchangeShape rows_exchange_shape(int log2n2, size_t world, size_t chunks) {
+    RowsExchangeShape q{};
+    q.la = (log2n2 + 1) / 2, q.lb = log2n2 - q.la;
+    const size_t n2 = static_cast<size_t>(1) << log2n2;
+    q.na = static_cast<size_t>(1) << q.la, q.nb = static_cast<size_t>(1) << q.lb;
+    q.ok = false;
+    if (q.la > 8 || q.lb < 4 || world == 0 || (world & (world - 1)) || n2 % world || chunks == 0 || (chunks & (chunks - 1))) return q;
+    q.C = n2 / world;
+    q.cols1 = (q.la >= 7 && q.nb % (2 * kTile / q.na) == 0 ? 2 : 1) * kTile / q.na;  // columns per workgroup, pass 1
+    q.cols2 = (q.lb >= 7 && q.na % (2 * kTile / q.nb) == 0 ? 2 : 1) * kTile / q.nb;
+    // a column chunk must hold whole runs of n2b (the chunk index is then a bit field of n2a)
+    q.ok = q.C >= q.na && q.nb % q.cols1 == 0 && q.na % q.cols2 == 0 && q.C % chunks == 0 && (q.C / chunks) % q.nb == 0;
+    return q;
+}
+}  // namespace
+
+bool fft_rows_exchange_covers(int log2n2, size_t world, size_t chunks) { return rows_exchange_shape(log2n2, world, chunks).ok; }
+
+bool fft_columns_tiled(int log2n, size_t cols) {
+    const int la = log2n <= 8 ? log2n : (log2n + 1) / 2, lb = log2n <= 8 ? 0 : log2n - la;
+    const size_t na = static_cast<size_t>(1) << la, nb = static_cast<size_t>(1) << lb;
+    return (nb * cols) % (kTile >> la) == 0 && (lb == 0 || (na * cols) % (kTile >> lb) == 0);
+}
+
+int launch_fft_rows_exchange_chunk(const float2 *in_f2, float2 *out_f2, int log2n2, size_t rows, size_t world, int tw_log2n,
+                                   unsigned long long row0, int direction, hipStream_t s, size_t chunks, size_t rows_total,
+                                   size_t row_off) {
     const c32 *in = reinterpret_cast<const c32 *>(in_f2);
     c32 *out = reinterpret_cast<c32 *>(out_f2);
-    const int la = (log2n2 + 1) / 2, lb = log2n2 - la;
-    const size_t n2 = static_cast<size_t>(1) << log2n2, na = static_cast<size_t>(1) << la, nb = static_cast<size_t>(1) << lb;
-    if (la > 8 || lb < 4 || world == 0 || (world & (world - 1)) || n2 % world)
+    const RowsExchangeShape q = rows_exchange_shape(log2n2, world, chunks);
+    if (q.la > 8 || q.lb < 4 || world == 0 || (world & (world - 1)) || (static_cast<size_t>(1) << log2n2) % world)
         return fail(DSP_GPU_EUNSUPPORTED, "fft_rows_exchange: 2^%d columns over %zu ranks", log2n2, world);
-    const size_t C = n2 / world;
-    const size_t cols1 = (la >= 7 && nb % (2 * kTile / na) == 0 ? 2 : 1) * kTile / na;  // columns per workgroup, pass 1
-    const size_t cols2 = (lb >= 7 && na % (2 * kTile / nb) == 0 ? 2 : 1) * kTile / nb;
-    if (C < na || nb % cols1 || na % cols2 || in == out)
+    if (!q.ok || in == out || row_off + rows > rows_total)
         return fail(DSP_GPU_EUNSUPPORTED, "fft_rows_exchange: shape not covered by the fused passes");
+    const size_t n2 = static_cast<size_t>(1) << log2n2, na = q.na, nb = q.nb, C = q.C, Cc = C / chunks;
     void *scratch_v = nullptr;
     if (int rc = workspace(WS_SCRATCH_A, rows * n2 * sizeof(c32), &scratch_v)) return rc;
     c32 *scratch = static_cast<c32 *>(scratch_v);
-    int ilog = 0, olog = 0;
-    while ((nb << ilog) < C) ++ilog;  // n2a values per received block
-    while ((na << olog) < C) ++olog;  // k2b values per block to send
+    int rlog = 0, klog = 0, olog = 0;
+    while ((nb << rlog) < Cc) ++rlog;                        // n2a values per (sender, column chunk)
+    while ((static_cast<size_t>(1) << klog) < chunks) ++klog;  // column chunks per sender
+    while ((na << olog) < C) ++olog;                         // k2b values per block to send
+    // n2 = n2a*nb + n2b = g*C + i*Cc + rest*nb + n2b  ->  in[i][g][row][rest*nb + n2b]
     ColumnPlan p1{nb, 1, na, 1, log2n2};
-    p1.in_a = C;
+    p1.in_a = Cc;
     p1.in_lo = nb;
-    p1.in_hi = rows * C;
-    p1.in_split = ilog;
+    p1.in_split = rlog;
+    p1.in_mid = world * rows_total * Cc;
+    p1.in_mid_bits = klog;
+    p1.in_hi = rows_total * Cc;
     p1.in_tw_log2 = tw_log2n;
-    p1.in_tw_row0 = row0;
-    if (int rc = launch_column(la, in, scratch, p1, rows, direction, s)) return rc;
+    p1.in_tw_row0 = row0 + row_off;
+    if (int rc = launch_column(q.la, in + row_off * Cc, scratch, p1, rows, direction, s)) return rc;
     ColumnPlan p2{na, na, 0, na, 0};
     p2.out_a = C;
     p2.out_hi = rows * C;
     p2.out_split = olog;
-    return launch_column(lb, scratch, out, p2, rows, direction, s);
+    return launch_column(q.lb, scratch, out, p2, rows, direction, s);
+}
+
+int launch_fft_rows_exchange(const float2 *in_f2, float2 *out_f2, int log2n2, size_t rows, size_t world, int tw_log2n,
+                             unsigned long long row0, int direction, hipStream_t s) {
+    return launch_fft_rows_exchange_chunk(in_f2, out_f2, log2n2, rows, world, tw_log2n, row0, direction, s, 1, rows, 0);
 }
 
 // DSP_GPU_REAL_HALF_14=0/1 (A/B): whether rows of 2^14 real samples take the half-length form too

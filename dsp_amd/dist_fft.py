@@ -139,14 +139,22 @@ class NativePlan:
                                                                int(inverse), self._stream(t)))
         return out
 
-    def run(self, t, inverse: bool = False, out=None, transposed: bool = False):
+    def flags(self, transposed: bool = False, serial: bool = False) -> int:
+        return (self.capi.DIST_TRANSPOSED_OUT if transposed else 0) | (self.capi.DIST_SERIAL if serial else 0)
+
+    def exchanges(self, transposed: bool = False, serial: bool = False) -> int:
+        """How many times one transform calls the plan's exchange (chunks of the pipelined schedule x 3 or 2)."""
+        return int(self.capi.lib().dsp_gpu_fft_dist_exchanges(self._handle, self.flags(transposed, serial)))
+
+    def run(self, t, inverse: bool = False, out=None, transposed: bool = False, serial: bool = False):
         """The whole transform through dsp_gpu_fft_dist_ex (exchange callback or RCCL communicator of the plan).
-        transposed: keep the spectrum as out[r][k2] = X[(rank*N1/G + r) + N1*k2] -- one exchange and one pass fewer."""
+        transposed: keep the spectrum as out[r][k2] = X[(rank*N1/G + r) + N1*k2] -- one exchange and one pass fewer.
+        serial: the unpipelined schedule (every exchange on the caller's stream, nothing overlaps)."""
         if t.numel() != self.local_points:
             raise ValueError("x_local must hold N / world points")
         out = self.torch.empty_like(t) if out is None else out
         rc = self.capi.lib().dsp_gpu_fft_dist_ex(self._handle, t.data_ptr(), out.data_ptr(), int(inverse),
-                                                 self.capi.DIST_TRANSPOSED_OUT if transposed else 0, self._stream(t))
+                                                 self.flags(transposed, serial), self._stream(t))
         err, self._error = getattr(self, "_error", None), None
         if err is not None:
             raise err

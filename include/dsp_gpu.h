@@ -211,21 +211,30 @@ int dsp_gpu_fft_rows_exchange(const void *in, void *out, int log2n2, size_t rows
  * receives X[g*N/G, (g+1)*N/G), natural order, in `out`; both are DEVICE buffers of
  * dsp_gpu_fft_dist_local_points(plan) = N/G complex fp32 points, in != out, `in` is not modified.
  * 8 <= log2n <= 32; N1 = 2^ceil(log2n/2) and N2 = N/N1 must both be multiples of `world`, N2/world >= 2.
- * Collective: every rank calls dsp_gpu_fft_dist with the same log2n and direction.  The plan owns one work buffer
- * of N/G points on the device current at its first use (freed by dsp_gpu_fft_dist_plan_destroy); calls on one
- * plan must not overlap.
+ * Collective: every rank calls dsp_gpu_fft_dist with the same log2n, direction and flags.  The plan owns up to two work
+ * buffers of N/G points, a stream and a few events on the device current at its first use (freed by
+ * dsp_gpu_fft_dist_plan_destroy); calls on one plan must not overlap.
  *
- *   dsp_gpu_fft_dist_plan_create       `exchange` performs the all-to-all between phases: block g (block_bytes
- *                                      bytes) of `send` goes to rank g, block g of `recv` comes from rank g, ordered
- *                                      on `stream`; device pointers; returns 0 or a negative DSP_GPU_E* code.  It is
- *                                      called three times per transform.  NULL: only dsp_gpu_fft_dist_phase (or
- *                                      world == 1) can be used.
+ *   dsp_gpu_fft_dist_plan_create       `exchange` performs one all-to-all: block g (block_bytes bytes) of `send` goes
+ *                                      to rank g, block g of `recv` comes from rank g, enqueued on `stream` -- which
+ *                                      is the caller's stream in the serial schedule and a stream of the plan's own in
+ *                                      the pipelined one; device pointers; returns 0 or a negative DSP_GPU_E* code.
+ *                                      Once the work it enqueued on `stream` has run, `recv` must be complete AND
+ *                                      `send` free to be overwritten (grouped ncclSend/ncclRecv, an MPI all-to-all
+ *                                      followed by a stream callback ... behave so).  Every rank's exchange is called
+ *                                      the same number of times in the same order: dsp_gpu_fft_dist_exchanges() per
+ *                                      transform.  NULL: only dsp_gpu_fft_dist_phase (or world == 1) can be used.
  *   dsp_gpu_fft_dist_plan_create_rccl  the built-in exchange: grouped ncclSend/ncclRecv on the caller's
  *                                      communicator (an ncclComm_t whose rank/size equal rank/world) -- one block
  *                                      per peer over the xGMI mesh.  librccl is looked up at run time (dlopen);
  *                                      DSP_GPU_EUNSUPPORTED when it is not there.
  *   dsp_gpu_fft_dist                   the whole transform: four local phases, three exchanges (skipped when
- *                                      world == 1 and the plan has no exchange).
+ *                                      world == 1 and the plan has no exchange).  When the shape allows it (N/G cut
+ *                                      into 4 or 2 chunks that still fill the kernels' tiles) the schedule is
+ *                                      PIPELINED: pack, first exchange, transform over n1 and second exchange run per
+ *                                      chunk of columns, transform over n2, third exchange and final transpose per
+ *                                      chunk of rows, the exchanges on the plan's stream so that exchange k of one
+ *                                      chunk overlaps the local pass of the next.  Same result bit for bit.
  *   dsp_gpu_fft_dist_phase             one local phase (0 pack, 1 FFT over n1, 2 twiddle + FFT over n2 + pack,
  *                                      3 transpose to natural order) for hosts that run the exchange themselves
  *                                      between phases (dsp_amd/dist_fft.py: torch.distributed all_to_all_single).
@@ -246,6 +255,9 @@ int dsp_gpu_fft_dist(dsp_gpu_fft_dist_plan *plan, const void *in, void *out, int
  * A plan without an exchange (one rank) also skips the pack in front of the first exchange, a plain copy there.
  */
 #define DSP_GPU_DIST_TRANSPOSED_OUT 1
+#define DSP_GPU_DIST_SERIAL 2 /* the unpipelined schedule: phase, exchange, phase ... on the caller's stream alone */
+/* number of times a transform with these flags calls the plan's exchange (0 without one) */
+int dsp_gpu_fft_dist_exchanges(const dsp_gpu_fft_dist_plan *plan, int flags);
 int dsp_gpu_fft_dist_ex(dsp_gpu_fft_dist_plan *plan, const void *in, void *out, int direction, int flags, void *stream);
 int dsp_gpu_fft_dist_phase(dsp_gpu_fft_dist_plan *plan, int phase, const void *in, void *out, int direction,
                            void *stream);

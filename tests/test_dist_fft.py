@@ -43,6 +43,17 @@ class NumpyLocalOps:
         return self._t(self._np(t).reshape(blocks, rows, cols).transpose(2, 0, 1))
 
 
+_SPECTRA = {}
+
+
+def _oracle_spectrum(orc, x, log2n, inverse):
+    """orc.fft0 of the callback tests' signal, kept across their parameter combinations (2^24 points take seconds)."""
+    key = (log2n, bool(inverse))
+    if key not in _SPECTRA:
+        _SPECTRA[key] = orc.fft0(x.astype(np.complex128), inverse)
+    return _SPECTRA[key]
+
+
 def _signal(log2n, seed=2030):
     rng = np.random.default_rng(seed)
     n = 1 << log2n
@@ -286,100 +297,160 @@ def test_native_plan_transposed_out_world_of_one(dev, log2n):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("serial", [False, True])
 @pytest.mark.parametrize("transposed", [False, True])
-@pytest.mark.parametrize("log2n,world", [(16, 2), (20, 4), (18, 8), (22, 8)])
-def test_native_plan_with_exchange_callback(orc, dev, log2n, world, transposed):
-    """dsp_gpu_fft_dist with a caller-supplied exchange: `world` host threads, one plan each, on one GPU and one
-    stream.  The callback trades blocks with device copies.  A baton keeps one thread at a time inside the
-    library (calls that use the library's scratch must not overlap on a device)."""
+@pytest.mark.parametrize("log2n,world", [(16, 2), (20, 4), (18, 8), (22, 8), (24, 1), (24, 2), (24, 8)])
+def test_native_plan_with_exchange_callback(orc, dev, log2n, world, transposed, serial):
+    """dsp_gpu_fft_dist_ex with a caller-supplied exchange: `world` host threads, one plan each, on one GPU.  The
+    callback trades blocks with device copies on the stream it is handed (the caller's in the serial schedule, the
+    plan's own in the pipelined one) and honours the contract of include/dsp_gpu.h with events: a receiver copies only
+    once the sender's stream has produced the block, and a sender's stream moves on only once every receiver has
+    copied.  A baton keeps one thread at a time inside the library (calls that use the library's scratch must not
+    overlap on a device).  Pipelined and serial schedules must agree bit for bit."""
     import ctypes as C
     import threading
     import torch
     from dsp_amd import dist_fft
     hip = C.CDLL("libamdhip64.so")
     hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
-    D2D = 3
+    hip.hipEventCreateWithFlags.argtypes = [C.POINTER(C.c_void_p), C.c_uint]
+    hip.hipEventRecord.argtypes = [C.c_void_p, C.c_void_p]
+    hip.hipStreamWaitEvent.argtypes = [C.c_void_p, C.c_void_p, C.c_uint]
+    hip.hipEventDestroy.argtypes = [C.c_void_p]
+    D2D, NO_TIMING = 3, 2
     x = _signal(log2n, seed=7 + log2n)
     stream = torch.cuda.current_stream(dev).cuda_stream
     baton, barrier = threading.Lock(), threading.Barrier(world)
-    sends = [[None] * world for _ in range(3)]
+    max_calls = 12
+    sends = [[None] * world for _ in range(max_calls)]
     calls = [0] * world
     errors = []
+
+    def new_event():
+        e = C.c_void_p()
+        assert hip.hipEventCreateWithFlags(C.byref(e), NO_TIMING) == 0
+        return e
+
+    ready = [[new_event() for _ in range(world)] for _ in range(max_calls)]
+    done = [[new_event() for _ in range(world)] for _ in range(max_calls)]
+
+    def rendezvous():
+        baton.release()
+        try:
+            barrier.wait(timeout=60)
+        finally:
+            baton.acquire()
 
     def make_exchange(rank):
         def exchange(send, recv, nbytes, w, s):
             k = calls[rank]
             calls[rank] += 1
             sends[k][rank] = send
-            baton.release()
-            try:
-                barrier.wait(timeout=60)
-            finally:
-                baton.acquire()
-            rc = 0
+            rc = 0 if hip.hipEventRecord(ready[k][rank], s) == 0 else -2  # my blocks are ready at this point of my stream
+            rendezvous()
             for src in range(w):  # block `rank` of every sender, in sender order
+                if hip.hipStreamWaitEvent(s, ready[k][src], 0) != 0:
+                    rc = -2
                 if hip.hipMemcpyAsync(recv + src * nbytes, sends[k][src] + rank * nbytes, nbytes, D2D, s) != 0:
                     rc = -2
-            # nobody may enqueue its next phase (which overwrites its send buffer) before every rank's copies are
-            # enqueued; after that, stream order keeps it safe
-            baton.release()
-            try:
-                barrier.wait(timeout=60)
-            finally:
-                baton.acquire()
+            if hip.hipEventRecord(done[k][rank], s) != 0:
+                rc = -2
+            rendezvous()
+            for dst in range(w):  # my send buffer is free once every receiver has copied its block out of it
+                if hip.hipStreamWaitEvent(s, done[k][dst], 0) != 0:
+                    rc = -2
             return rc
         return exchange
 
-    for inverse in (False, True):
-        parts = [torch.from_numpy(p.copy()).to(dev) for p in np.split(x, world)]
-        outs = [torch.empty_like(p) for p in parts]
-        for c in range(world):
-            calls[c] = 0
-        plans = [dist_fft.NativePlan(log2n, r, world, exchange=make_exchange(r)) for r in range(world)]
+    try:
+        for inverse in (False, True):
+            parts = [torch.from_numpy(p.copy()).to(dev) for p in np.split(x, world)]
+            outs = [torch.full_like(p, float("nan")) for p in parts]
+            for c in range(world):
+                calls[c] = 0
+            plans = [dist_fft.NativePlan(log2n, r, world, exchange=make_exchange(r)) for r in range(world)]
+            flags = plans[0].flags(transposed, serial)
+            expected = plans[0].exchanges(transposed, serial)
+            assert expected == (2 if transposed else 3) or (not serial and expected in (4, 6, 8, 12))
+            if log2n >= 24 and not serial:
+                assert expected > 3, "a transform of this size is expected to take the pipelined schedule"
 
-        def worker(r):
-            torch.cuda.set_device(dev)
-            with baton:
-                try:
-                    plans[r].capi.check(plans[r].capi.lib().dsp_gpu_fft_dist_ex(plans[r]._handle, parts[r].data_ptr(),
-                                                                               outs[r].data_ptr(), int(inverse),
-                                                                               1 if transposed else 0, stream))
-                except Exception as e:  # noqa: BLE001
-                    errors.append(e)
-                    barrier.abort()
+            def worker(r):
+                torch.cuda.set_device(dev)
+                with baton:
+                    try:
+                        plans[r].capi.check(plans[r].capi.lib().dsp_gpu_fft_dist_ex(plans[r]._handle, parts[r].data_ptr(),
+                                                                                   outs[r].data_ptr(), int(inverse), flags, stream))
+                    except Exception as e:  # noqa: BLE001
+                        errors.append(e)
+                        barrier.abort()
 
-        threads = [threading.Thread(target=worker, args=(r,)) for r in range(world)]
-        for t in threads:
-            t.start()
-        for t in threads:
-            t.join(timeout=120)
+            threads = [threading.Thread(target=worker, args=(r,)) for r in range(world)]
+            for t in threads:
+                t.start()
+            for t in threads:
+                t.join(timeout=120)
+            torch.cuda.synchronize()
+            assert not errors, errors
+            assert calls == [expected] * world
+            got = torch.cat(outs).cpu().numpy()
+            want = _oracle_spectrum(orc, x, log2n, inverse)
+            if transposed:  # the ranks' row blocks stacked: [k1][k2] = X[k1 + N1 k2]
+                n1 = 1 << ((log2n + 1) // 2)
+                want = want.reshape(-1, n1).T.reshape(-1)
+            assert rel_l2(got, want) <= 1e-5 * log2n
+            if not serial and expected > 3:  # the serial schedule runs the same kernels on the same values
+                for c in range(world):
+                    calls[c] = 0
+                outs2 = [torch.full_like(p, float("nan")) for p in parts]
+                flags = plans[0].flags(transposed, True)
+
+                def worker2(r):
+                    torch.cuda.set_device(dev)
+                    with baton:
+                        try:
+                            plans[r].capi.check(plans[r].capi.lib().dsp_gpu_fft_dist_ex(plans[r]._handle, parts[r].data_ptr(),
+                                                                                       outs2[r].data_ptr(), int(inverse), flags, stream))
+                        except Exception as e:  # noqa: BLE001
+                            errors.append(e)
+                            barrier.abort()
+
+                threads = [threading.Thread(target=worker2, args=(r,)) for r in range(world)]
+                for t in threads:
+                    t.start()
+                for t in threads:
+                    t.join(timeout=120)
+                torch.cuda.synchronize()
+                assert not errors, errors
+                assert np.array_equal(torch.cat(outs2).cpu().numpy().view(np.uint32), got.view(np.uint32))
+            for p in plans:
+                p.close()
+    finally:
         torch.cuda.synchronize()
-        assert not errors, errors
-        assert calls == [2 if transposed else 3] * world
-        got = torch.cat(outs).cpu().numpy()
-        want = orc.fft0(x.astype(np.complex128), inverse)
-        if transposed:  # the ranks' row blocks stacked: [k1][k2] = X[k1 + N1 k2]
-            n1 = 1 << ((log2n + 1) // 2)
-            want = want.reshape(-1, n1).T.reshape(-1)
-        assert rel_l2(got, want) <= 1e-5 * log2n
-        for p in plans:
-            p.close()
+        for row in ready + done:
+            for e in row:
+                hip.hipEventDestroy(e)
 
 
 @pytest.mark.gpu
-def test_native_plan_rccl_world_of_one(dev, orc):
-    """The built-in exchange (grouped ncclSend/ncclRecv) on a communicator of one rank made with RCCL's own API."""
-    import ctypes as C
+@pytest.mark.parametrize("log2n", [16, 24])
+def test_native_plan_rccl_world_of_one(dev, orc, log2n):
+    """The built-in exchange (grouped ncclSend/ncclRecv) on a communicator of one rank made with RCCL's own API.
+    2^24 points take the pipelined schedule (exchanges on the plan's stream): same bits as the serial one."""
     import torch
     from dsp_amd import dist_fft
 
     comm = dist_fft.RcclCommunicator(0, 1)
     try:
-        log2n = 16
-        x = _signal(log2n)
+        x = _signal(log2n, seed=7 + log2n)
         plan = dist_fft.NativePlan(log2n, 0, 1, nccl_comm=comm.handle)
-        out = plan.run(torch.from_numpy(x).to(dev)).cpu().numpy()
-        assert rel_l2(out, orc.fft0(x.astype(np.complex128))) <= 1.6e-4
+        assert plan.exchanges() == (12 if log2n == 24 else 3)
+        xd = torch.from_numpy(x).to(dev)
+        out = plan.run(xd).cpu().numpy()
+        assert rel_l2(out, _oracle_spectrum(orc, x, log2n, False)) <= 1e-5 * log2n
+        assert np.array_equal(plan.run(xd, serial=True).cpu().numpy().view(np.uint32), out.view(np.uint32))
+        t = plan.run(xd, transposed=True)
+        assert torch.equal(t, plan.run(xd, transposed=True, serial=True))
         plan.close()
     finally:
         torch.cuda.synchronize()
