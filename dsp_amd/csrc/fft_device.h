@@ -92,6 +92,41 @@ constexpr float cos16(int q) {
 }
 constexpr float sin16(int q) { return cos16(q + 12); }  // sin(x) = cos(x - pi/2)
 
+constexpr float cos64(int q) {
+    constexpr float t[17] = {1.0f, 0.99518472667219693f, 0.98078528040323043f, 0.95694033573220882f,
+                             0.92387953251128674f, 0.88192126434835505f, 0.83146961230254524f, 0.77301045336273699f,
+                             0.70710678118654757f, 0.63439328416364549f, 0.55557023301960229f, 0.47139673682599781f,
+                             0.38268343236508984f, 0.29028467725446233f, 0.19509032201612833f, 0.09801714032956077f, 0.0f};
+    q &= 63;
+    return q <= 16 ? t[q] : (q <= 32 ? -t[32 - q] : (q <= 48 ? -t[q - 32] : t[64 - q]));
+}
+constexpr float sin64(int q) { return cos64(q + 48); }  // sin(x) = cos(x - pi/2)
+
+constexpr float cos128(int q) {
+    constexpr float t[33] = {1.0f, 0.99879545620517241f, 0.99518472667219693f, 0.98917650996478101f, 0.98078528040323043f,
+                             0.97003125319454397f, 0.95694033573220882f, 0.94154406518302081f, 0.92387953251128674f,
+                             0.90398929312344334f, 0.88192126434835505f, 0.85772861000027212f, 0.83146961230254524f,
+                             0.80320753148064494f, 0.77301045336273699f, 0.74095112535495911f, 0.70710678118654757f,
+                             0.67155895484701833f, 0.63439328416364549f, 0.59569930449243347f, 0.55557023301960229f,
+                             0.51410274419322166f, 0.47139673682599781f, 0.4275550934302822f, 0.38268343236508984f,
+                             0.33688985339222005f, 0.29028467725446233f, 0.24298017990326398f, 0.19509032201612833f,
+                             0.14673047445536175f, 0.09801714032956077f, 0.049067674327418126f, 0.0f};
+    q &= 127;
+    return q <= 32 ? t[q] : (q <= 64 ? -t[64 - q] : (q <= 96 ? -t[q - 64] : t[128 - q]));
+}
+constexpr float sin128(int q) { return cos128(q + 96); }  // sin(x) = cos(x - pi/2)
+
+// exp(2 pi i s / P) for the register counts in use (P points per thread)
+template <int P>
+constexpr float cos_per_points(int s) {
+    static_assert(P == 16 || P == 64, "points per thread");
+    return P == 16 ? cos16(s) : cos64(s);
+}
+template <int P>
+constexpr float sin_per_points(int s) {
+    return P == 16 ? sin16(s) : sin64(s);
+}
+
 // multiply by exp(SIGN * 2 pi i * Q / 16), Q a compile-time constant
 template <int Q, int SIGN>
 DSP_DEV c32 mul_w16(c32 a) {
@@ -231,10 +266,10 @@ DSP_DEV void stockham_pass(c32 (&r)[P], int lt) {
             c32 pw[R];
             if constexpr (B > 1 && NS * R == N) {
                 // last pass, several butterflies per thread: k_s = k_0 + T*s never wraps (lt < T, T*B = NS), and
-                // T*s / N = s/16, so W_N^{k_s} = W_N^{k_0} * W_16^s with W_16^s a compile-time constant: one sincospif
+                // T*s / N = s/P, so W_N^{k_s} = W_N^{k_0} * W_P^s with W_P^s a compile-time constant: one sincospif
                 // per thread instead of one per butterfly
                 const c32 w0 = unit_root<SIGN>(static_cast<unsigned>(lt) & (NS - 1), LOG2DEN);
-                pw[1] = s == 0 ? w0 : cmul(w0, c32{cos16(s), SIGN * sin16(s)});
+                pw[1] = s == 0 ? w0 : cmul(w0, c32{cos_per_points<P>(s), SIGN * sin_per_points<P>(s)});
             } else {
                 pw[1] = unit_root<SIGN>(k, LOG2DEN);
             }

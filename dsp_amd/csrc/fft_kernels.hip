@@ -242,6 +242,148 @@ __global__ __launch_bounds__((1 << LOG2N) / kPoints) void fft_big_kernel(const v
     }
 }
 
+// ---- 2^15 points in ONE pass through HBM -----------------------------------------------------------------------
+// 512 threads x 64 register-resident points; the complex image of the transform (256 KB) does not fit a CU's LDS, so the
+// points cross between passes one fp32 plane at a time (real parts, then imaginary parts) through a 136 KB image:
+// radix 16, 16, 16, 8 -- four passes, three exchanges of two planes each.  One workgroup per CU, persistent, XCD x owns
+// the contiguous range [x*chunk, (x+1)*chunk) of the batch.  Against the two-pass route (16 B + 16 B per point) this
+// is one read and one write of every point.
+// REAL_HALF: rows of 2^16 real samples ride the 2^15-point transform and the 2^16-bin spectrum is unfolded in the same
+// workgroup (see fft_big_kernel): 4 B read + 8 B written per sample instead of 8 + 12.
+constexpr int kPlanePoints = 64;
+constexpr int kPlaneLog2N = 15;
+constexpr int kPlaneThreads = (1 << kPlaneLog2N) / kPlanePoints;                        // 512
+constexpr size_t kPlaneLdsBytes = ((1 << kPlaneLog2N) + (1 << kPlaneLog2N) / 16) * sizeof(float);  // 139,264
+
+// scatter the outputs of the pass (radix 16 after sub-length NS), gather r[m] = element lt + T m; one plane at a time
+template <int NS>
+DSP_DEV void plane_exchange(c32 (&r)[kPlanePoints], float *lds, int lt) {
+    constexpr int R = 16, T = kPlaneThreads, B = kPlanePoints / R;
+    static_assert(NS == 1 || NS % 16 == 0, "sub-length");
+#pragma unroll
+    for (int part = 0; part < 2; ++part) {
+        __syncthreads();  // the image of the previous plane / exchange / transform has been read by everyone
+#pragma unroll
+        for (int s = 0; s < B; ++s) {
+            const int j = lt + T * s;
+            // padded(dest + u NS) is linear in u: 16 j + u -> 17 j + u (NS = 1), x + 16 k -> padded(x) + 17 k otherwise
+            float *w = lds + padded(stockham_dest<R, NS>(j, 0));
+#pragma unroll
+            for (int u = 0; u < R; ++u) w[NS == 1 ? u : u * (NS + NS / 16)] = part ? r[s + u * B].y : r[s + u * B].x;
+        }
+        __syncthreads();
+        const float *g = lds + padded(lt);
+#pragma unroll
+        for (int m = 0; m < kPlanePoints; ++m) {
+            const float v = g[m * (T + T / 16)];
+            if (part) r[m].y = v;
+            else r[m].x = v;
+        }
+    }
+}
+
+template <int SIGN, bool REAL_HALF, bool SHIFTED>
+__global__ __launch_bounds__(kPlaneThreads) void fft_plane_kernel(const void *__restrict__ in_, c32 *__restrict__ out,
+                                                                  size_t batch, size_t chunk, size_t n_in, size_t in_stride) {
+    constexpr int LOG2N = kPlaneLog2N, N = 1 << LOG2N, P = kPlanePoints, T = kPlaneThreads;
+    extern __shared__ __attribute__((aligned(16))) float plane_lds[];
+    const int lt = threadIdx.x;
+    const size_t per_xcd = gridDim.x >> 3;
+    const size_t lo = static_cast<size_t>(blockIdx.x & 7u) * chunk, hi = lo + chunk < batch ? lo + chunk : batch;
+    for (size_t t = lo + (blockIdx.x >> 3); t < hi; t += per_xcd) {
+        c32 r[P];
+        if constexpr (REAL_HALF) {
+            const float *src = static_cast<const float *>(in_) + t * in_stride;
+            const bool pairs = (in_stride & 1) == 0 && (reinterpret_cast<uintptr_t>(in_) & 7) == 0;
+            if (pairs && n_in >= static_cast<size_t>(2 * N)) {  // no padding, 8-byte aligned rows: the row IS the complex input
+#pragma unroll
+                for (int m = 0; m < P; ++m) r[m] = load_stream(reinterpret_cast<const c32 *>(src) + lt + T * m);
+            } else {
+                // zero padding (fft.h:65-74) by the hardware: buffer loads of a descriptor that ends with the row return 0
+                // beyond it -- no branch around any load, no lane masks, all loads in flight together
+                const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(src), 0,
+                                                                    static_cast<int>(n_in < 2 * static_cast<size_t>(N) ? n_in : 2 * N) * 4, 0x00020000);
+                int lo8 = 8 * lt;  // laundered: 128 loop-invariant offsets hoisted out of the persistent loop would be spilled
+                asm volatile("" : "+v"(lo8));
+#pragma unroll
+                for (int m = 0; m < P; ++m) {
+                    const int off = lo8 + 8 * T * m;
+                    r[m] = mk(__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, off, 0, 0)),
+                              __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, off + 4, 0, 0)));
+                }
+            }
+        } else {
+            const c32 *src = static_cast<const c32 *>(in_) + t * N;
+#pragma unroll
+            for (int m = 0; m < P; ++m) r[m] = load_stream(src + lt + T * m);
+        }
+        stockham_pass<16, 1, LOG2N, SIGN, P>(r, lt);
+        plane_exchange<1>(r, plane_lds, lt);
+        stockham_pass<16, 16, LOG2N, SIGN, P>(r, lt);
+        plane_exchange<16>(r, plane_lds, lt);
+        stockham_pass<16, 256, LOG2N, SIGN, P>(r, lt);
+        plane_exchange<256>(r, plane_lds, lt);
+        stockham_pass<8, 4096, LOG2N, SIGN, P>(r, lt);
+        if constexpr (REAL_HALF) {
+            // Z[k], k = lt + T m, in natural order through the image once more, a plane at a time: bin k needs Z[N - k].
+            // With zc = conj Z[N - k]:  E = (Z + zc)/2, i O = (Z - zc)/2, X[k] = E + W_2N^k O, X[k + N] = E - W_2N^k O.
+            // The image addresses do not depend on the transform; recomputed from a laundered copy of the thread index so
+            // that they are not hoisted out of the persistent loop (64 + 64 address registers held across all passes).
+            int lv = lt;
+            asm volatile("" : "+v"(lv));
+            float *own = plane_lds + padded(lv);
+            // N - k = (T - lt) + T (63 - m) for lt > 0; thread 0: T (64 - m), and bin 0 mirrors itself.
+            // padded(x + T j) = padded(x) + (T + T/16) j.
+            const float *mir = plane_lds + padded(T - lv);
+            constexpr int kRow = T + T / 16;
+            float dx[P];
+            __syncthreads();
+#pragma unroll
+            for (int m = 0; m < P; ++m) own[m * kRow] = r[m].x;
+            __syncthreads();
+#pragma unroll
+            for (int m = 0; m < P; ++m) {
+                if (m % 8 == 0) __builtin_amdgcn_sched_barrier(0);  // as below: eight image reads in flight, not 64
+                const float zx = m == 0 ? (lv ? mir[63 * kRow] : plane_lds[0]) : mir[(63 - m) * kRow];
+                dx[m] = 0.5f * (r[m].x - zx);
+                r[m].x = 0.5f * (r[m].x + zx);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int m = 0; m < P; ++m) own[m * kRow] = r[m].y;
+            __syncthreads();
+            // W_2N^k = W_2N^lt * W_128^m (T / 2N = 1/128): one sincos per thread, the rest compile-time constants
+            const c32 w0 = unit_root<SIGN>(static_cast<unsigned>(lv), LOG2N + 1);
+            c32 *row = out + t * (2 * static_cast<size_t>(N)) + lv;
+#pragma unroll
+            for (int m = 0; m < P; ++m) {
+                // keep the image reads next to their use: all 64 hoisted to the top would need 64 more registers
+                if (m % 8 == 0) __builtin_amdgcn_sched_barrier(0);
+                const float zy = m == 0 ? (lv ? mir[63 * kRow] : plane_lds[0]) : mir[(63 - m) * kRow];
+                const c32 e = mk(r[m].x, 0.5f * (r[m].y - zy));
+                const c32 o = mk(0.5f * (r[m].y + zy), -dx[m]);   // O = -i (i O)
+                c32 w = w0;
+                if (m) {
+                    c32 k = c32{cos128(m), SIGN * sin128(m)};
+                    asm volatile("" : "+s"(k));  // materialised here, not kept in scalar registers across the loop
+                    w = cmul_k(w0, k);
+                }
+                const c32 wo = cmul(o, w);
+                // dsp::shift fused (fft.h:85-94): the halves of the 2N-bin row change places
+                store_stream(row + T * m + (SHIFTED ? N : 0), e + wo);
+                store_stream(row + T * m + (SHIFTED ? 0 : N), e - wo);
+            }
+        } else {
+#pragma unroll
+            for (int m = 0; m < P; ++m) {
+                int k = lt + T * m;
+                if constexpr (SHIFTED) k = (k + N / 2) & (N - 1);
+                store_stream(out + t * N + k, r[m]);
+            }
+        }
+    }
+}
+
 template <int LOG2N, int SIGN, bool REAL_IN, bool SHIFTED>
 __global__ __launch_bounds__(kThreads) void fft_tiny_kernel(const void *__restrict__ in_, c32 *__restrict__ out,
                                                             size_t batch, size_t n_in, size_t in_stride) {
@@ -650,6 +792,27 @@ int launch_big(const void *in, c32 *out, size_t batch, size_t n_in, size_t in_st
 }
 }  // namespace
 
+namespace {
+template <bool REAL_HALF, bool SHIFTED>
+int launch_plane(const void *in, c32 *out, size_t batch, size_t n_in, size_t in_stride, int direction, hipStream_t s) {
+    const size_t chunk = (batch + 7) / 8;
+    const size_t per_xcd = std::min<size_t>(chunk, 32);  // one resident workgroup per CU
+    auto kf = fft_plane_kernel<+1, REAL_HALF, SHIFTED>;
+    auto ki = fft_plane_kernel<-1, REAL_HALF, SHIFTED>;
+    auto kern = direction == DSP_GPU_FORWARD ? kf : ki;
+    if (int rc = allow_full_lds(reinterpret_cast<const void *>(kern))) return rc;
+    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(8 * per_xcd)), dim3(kPlaneThreads), kPlaneLdsBytes, s, in, out, batch, chunk,
+                       n_in, in_stride);
+    return check_launch("fft_plane_kernel");
+}
+
+// DSP_GPU_FFT_PLANE=0 (A/B, tests of both): 2^15-point transforms (and rows of 2^16 real samples) take the two-pass route
+bool plane_route() {
+    const char *e = getenv("DSP_GPU_FFT_PLANE");
+    return !e || e[0] != '0';
+}
+}  // namespace
+
 int launch_fft_batch(const float2 *in_f2, float2 *out_f2, int log2n, size_t batch, int direction, hipStream_t s) {
     const c32 *in = reinterpret_cast<const c32 *>(in_f2);
     c32 *out = reinterpret_cast<c32 *>(out_f2);
@@ -657,6 +820,7 @@ int launch_fft_batch(const float2 *in_f2, float2 *out_f2, int log2n, size_t batc
     if (log2n <= 12) return dispatch_small<false, false>(log2n, in, out, batch, 0, 0, direction, s);
     if (log2n == 13) return launch_big<13, false, false>(in, out, batch, 0, 0, direction, s);  // one HBM pass: 338 against 187 GSamples/s
     if (log2n == 14) return launch_big<14, false, false>(in, out, batch, 0, 0, direction, s);  //               317 against 190
+    if (log2n == 15 && plane_route()) return launch_plane<false, false>(in, out, batch, 0, 0, direction, s);
     return launch_large(in, out, log2n, batch, direction, s);
 }
 
@@ -809,6 +973,9 @@ int launch_fft_real_batch(const float *in, size_t n_in, size_t in_stride, float2
         return shifted ? launch_big<14, true, true>(in, out, batch, n_in, in_stride, direction, s)
                        : launch_big<14, true, false>(in, out, batch, n_in, in_stride, direction, s);
     }
+    if (log2n == 16 && real_half_large() && plane_route())  // 2^16 real samples ride one 2^15-point transform: a single HBM pass
+        return shifted ? launch_plane<true, true>(in, out, batch, n_in, in_stride, direction, s)
+                       : launch_plane<true, false>(in, out, batch, n_in, in_stride, direction, s);
     if (real_half_large())  // the rows ride a half-length complex transform; the last pass unfolds (and shifts) the spectrum
         return launch_large(nullptr, out, log2n - 1, batch, direction, s, in, n_in, in_stride, nullptr, shifted ? 2 : 1);
     const size_t n = static_cast<size_t>(1) << log2n;
@@ -855,7 +1022,8 @@ size_t fft_noalloc_max_points() { return kNoAllocPoints; }
 
 int launch_fft_batch_noalloc(const float2 *in_f2, float2 *out_f2, int log2n, size_t batch, int direction, hipStream_t s) {
     if (batch == 0) return DSP_GPU_OK;
-    if (log2n <= 14) return launch_fft_batch(in_f2, out_f2, log2n, batch, direction, s);  // single pass: no scratch at all
+    if (log2n <= 14 || (log2n == 15 && plane_route()))  // single pass: no scratch at all
+        return launch_fft_batch(in_f2, out_f2, log2n, batch, direction, s);
     if (batch > (kNoAllocPoints >> log2n))
         return fail(DSP_GPU_EINVAL, "dsp_gpu_fft_batch_noalloc: %zu transforms of 2^%d points exceed the fixed scratch of 2^21 points",
                     batch, log2n);

@@ -20,16 +20,6 @@ constexpr int kWaveRow = 65;                    // dwords per row of the transpo
                                                 // stores and the column-wise loads hit 32 distinct banks per half wave
 constexpr int kWaveLdsFloats = 64 * kWaveRow;   // one fp32 plane (re and im cross one after the other): 16,640 B
 
-constexpr float cos64(int q) {
-    constexpr float t[17] = {1.0f, 0.99518472667219693f, 0.98078528040323043f, 0.95694033573220882f,
-                             0.92387953251128674f, 0.88192126434835505f, 0.83146961230254524f, 0.77301045336273699f,
-                             0.70710678118654757f, 0.63439328416364549f, 0.55557023301960229f, 0.47139673682599781f,
-                             0.38268343236508984f, 0.29028467725446233f, 0.19509032201612833f, 0.09801714032956077f, 0.0f};
-    q &= 63;
-    return q <= 16 ? t[q] : (q <= 32 ? -t[32 - q] : (q <= 48 ? -t[q - 32] : t[64 - q]));
-}
-constexpr float sin64(int q) { return cos64(q + 48); }  // sin(x) = cos(x - pi/2)
-
 // multiply by exp(SIGN * 2 pi i * q / 64); q is a constant once the caller's loops are unrolled
 template <int SIGN>
 DSP_DEV c32 mul_w64(c32 a, int q) {

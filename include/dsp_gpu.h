@@ -24,11 +24,11 @@
  *     current (hipSetDevice) before the call.  Thread-safe in the sense that the library's own tables
  *     (tap cache, IIR plans) are locked and handed out pinned; but the per-device WORKSPACES are shared,
  *     not keyed per stream, so calls that use one must not overlap on one device (from two threads or
- *     two streams): every DSP_GPU_MEM_HOST call (staging), FFTs above 2^14 points, dsp_gpu_fft_columns,
+ *     two streams): every DSP_GPU_MEM_HOST call (staging), FFTs above 2^15 points, dsp_gpu_fft_columns,
  *     dsp_gpu_fft_rows_exchange, dsp_gpu_convolve_stream (history scratch), dsp_gpu_iir with `state` or in
  *     a SCAN form that carries tile states, dsp_gpu_iir_multi from host memory, and
  *     dsp_gpu_fft_batch_noalloc (its fixed array).  Calls that touch no workspace -- device-pointer FFTs up
- *     to 2^14 points, dsp_gpu_convolve, dsp_gpu_moving_average, dsp_gpu_iir BATCH without state -- may run
+ *     to 2^15 points, dsp_gpu_convolve, dsp_gpu_moving_average, dsp_gpu_iir BATCH without state -- may run
  *     concurrently on different streams.
  */
 #ifndef DSP_GPU_H
@@ -83,10 +83,10 @@ int dsp_gpu_fft_batch(const void *in, void *out, int log2n, size_t batch, int di
  * The allocation-free form of dsp_gpu_fft_batch.  NO COUNTERPART IN THE REFERENCE: it exists for callers that cannot
  * allocate device memory -- code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  Same
  * arithmetic and kernels as dsp_gpu_fft_batch on DEVICE pointers, asynchronous on `stream`, but the scratch buffer that
- * transforms of more than 2^14 points ping-pong through is a fixed 16 MiB device array inside the library (2^21 complex
+ * transforms of more than 2^15 points ping-pong through is a fixed 16 MiB device array inside the library (2^21 complex
  * points, held by every GPU the library runs on until the process ends) instead of the growing workspace, and the call
- * makes no hipMalloc / hipFree.  1 <= log2n <= 21; for log2n >= 15, batch * 2^log2n <= 2^21 points (DSP_GPU_EINVAL
- * beyond that; transforms of up to 2^14 points use no scratch and take any batch).  Every call on a GPU shares that
+ * makes no hipMalloc / hipFree.  1 <= log2n <= 21; for log2n >= 16, batch * 2^log2n <= 2^21 points (DSP_GPU_EINVAL
+ * beyond that; transforms of up to 2^15 points use no scratch and take any batch).  Every call on a GPU shares that
  * GPU's array: calls that overlap on one GPU (two streams, two threads) race.  The first call on a device looks up the
  * array's address (hipGetSymbolAddress) -- make it once outside a graph capture.
  */

@@ -263,3 +263,61 @@ def test_real_half_length_route_equals_full_length(ops, dev, log2n, monkeypatch)
     X = got["1"][0]
     assert float((X[:, 1:] - X[:, 1:].flip(1).conj()).abs().max()) <= 1e-3 * float(X.abs().max())
     assert float((X[:, 0].real - x.double().sum(1).float()).abs().max()) <= 2e-3 * float(x.abs().sum(1).max()) ** 0.5 + 1e-1
+
+
+@pytest.mark.parametrize("batch", [1, 5, 300])
+def test_single_pass_32768_points_equals_two_pass(ops, dev, orc, batch, monkeypatch):
+    """2^15-point transforms take one trip through HBM (fft_plane_kernel: 512 threads x 64 points, the points cross
+    between passes one fp32 plane at a time); DSP_GPU_FFT_PLANE=0 keeps the two-pass route.  Both against the oracle,
+    against each other, forward / inverse round trip and in place."""
+    import torch
+    g = torch.Generator(device=dev).manual_seed(15 + batch)
+    n = 1 << 15
+    x = torch.view_as_complex(torch.randn(batch, n, 2, device=dev, generator=g))
+    got = {}
+    for plane in ("1", "0"):
+        monkeypatch.setenv("DSP_GPU_FFT_PLANE", plane)
+        got[plane] = (ops.fft0(x), ops.fft0(x, inverse=True))
+    monkeypatch.setenv("DSP_GPU_FFT_PLANE", "1")
+    for a, b in zip(got["1"], got["0"]):
+        den = torch.linalg.vector_norm(b.view(torch.float32).double())
+        assert float(torch.linalg.vector_norm((a - b).view(torch.float32).double()) / den) <= budget(15)
+    for row in (0, batch - 1):
+        want = orc.fft0(x[row].cpu().numpy().astype(np.complex128), False)
+        assert rel_l2(got["1"][0][row].cpu().numpy(), want) <= budget(15)
+    back = ops.fft0(got["1"][0], inverse=True)
+    assert float((back / n - x).abs().max()) <= 1e-4 * float(x.abs().max())
+    buf = x.clone()
+    ops.fft0(buf, out=buf)
+    assert torch.equal(buf, got["1"][0])
+
+
+@pytest.mark.parametrize("n_in", [65536, 65531, 40000, 3])
+@pytest.mark.parametrize("shift", [False, True])
+def test_real_65536_single_pass_equals_other_routes(ops, dev, orc, n_in, shift, monkeypatch):
+    """Rows of 2^16 real samples (eval/modulation/helper.h:43's size) ride the single-pass 2^15-point transform, spectrum
+    unfolded in the same workgroup; zero padding comes from the buffer descriptor's bounds check.  Against the
+    two-pass half-length route, the full-length route and the oracle."""
+    import torch
+    g = torch.Generator(device=dev).manual_seed(n_in + int(shift))
+    x = torch.randn(9, n_in, device=dev, generator=g)
+    nf = 1 << 16
+    monkeypatch.setenv("DSP_GPU_FFT_PLANE", "1")
+    got = ops.fft(x, nf, shift=shift)
+    inv = ops.fft(x, nf, inverse=True, shift=shift)
+    monkeypatch.setenv("DSP_GPU_FFT_PLANE", "0")
+    two_pass = ops.fft(x, nf, shift=shift)
+    monkeypatch.setenv("DSP_GPU_REAL_HALF_LARGE", "0")
+    full = ops.fft(x, nf, shift=shift)
+    for other in (two_pass, full):
+        den = torch.linalg.vector_norm(other.view(torch.float32).double())
+        assert float(torch.linalg.vector_norm((got - other).view(torch.float32).double()) / den) <= budget(16)
+    padded = np.zeros(nf)
+    padded[:n_in] = x[8].cpu().numpy()
+    want = orc.fft0(padded.astype(np.complex128), False)
+    if shift:
+        want = np.roll(want, nf // 2)
+    assert rel_l2(got[8].cpu().numpy(), want) <= budget(16)
+    # the other direction of a real row is the conjugate spectrum
+    den = torch.linalg.vector_norm(got.view(torch.float32).double())
+    assert float(torch.linalg.vector_norm((inv - got.conj()).view(torch.float32).double()) / den) <= budget(16)

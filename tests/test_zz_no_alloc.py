@@ -24,7 +24,7 @@ def test_noalloc_matches_fft_batch_twice(dev, orc):
     from dsp_amd import capi
     L = capi.lib()
     g = torch.Generator(device=dev).manual_seed(77)
-    for log2n, batch in ((16, 8), (15, 3)):  # second call smaller than the first
+    for log2n, batch in ((17, 8), (16, 3)):  # second call smaller than the first (both sizes use the scratch array)
         n = 1 << log2n
         x = torch.view_as_complex(torch.randn(batch, n, 2, device=dev, generator=g))
         for direction in (capi.FORWARD, capi.INVERSE):
@@ -60,7 +60,7 @@ def test_noalloc_small_sizes_and_limits(dev):
     from dsp_amd import capi
     L = capi.lib()
     g = torch.Generator(device=dev).manual_seed(79)
-    for log2n, batch in ((12, 1000), (14, 300), (3, 17)):  # single-pass sizes: no scratch, any batch
+    for log2n, batch in ((12, 1000), (14, 300), (15, 100), (3, 17)):  # single-pass sizes: no scratch, any batch
         x = torch.view_as_complex(torch.randn(batch, 1 << log2n, 2, device=dev, generator=g))
         want = _run(L, capi, L.dsp_gpu_fft_batch, x, log2n, batch, capi.INVERSE)
         got = _run(L, capi, L.dsp_gpu_fft_batch_noalloc, x, log2n, batch, capi.INVERSE)
