@@ -23,6 +23,7 @@ DIST_SERIAL = 2
 # every symbol include/dsp_gpu.h declares (tests check the library exports all of them)
 EXPORTS = (
     "dsp_gpu_fft_batch",
+    "dsp_gpu_fft_batch_f64",
     "dsp_gpu_fft_batch_noalloc",
     "dsp_gpu_fft_real_batch",
     "dsp_gpu_convolve",
@@ -71,6 +72,8 @@ def lib() -> C.CDLL:
         L = C.CDLL(LIB_PATH)
         vp, sz, i = C.c_void_p, C.c_size_t, C.c_int
         L.dsp_gpu_fft_batch.argtypes = [vp, vp, i, sz, i, i, vp]
+        L.dsp_gpu_fft_batch_f64.argtypes = [vp, vp, i, sz, i, i, vp]
+        L.dsp_gpu_fft_batch_f64.restype = i
         L.dsp_gpu_fft_batch_noalloc.argtypes = [vp, vp, i, sz, i, vp]
         L.dsp_gpu_fft_batch_noalloc.restype = i
         L.dsp_gpu_fft_batch_timed.argtypes = [vp, vp, i, sz, i, i, C.POINTER(C.c_float), vp]

@@ -308,6 +308,22 @@ int dsp_gpu_fft_batch(const void *in, void *out, int log2n, size_t batch, int di
     });
 }
 
+int dsp_gpu_fft_batch_f64(const void *in, void *out, int log2n, size_t batch, int direction, int mem, void *stream) {
+    if (!in || !out) return fail(DSP_GPU_EINVAL, "dsp_gpu_fft_batch_f64: null buffer");
+    if (log2n < 1 || log2n > 24) return fail(DSP_GPU_EINVAL, "dsp_gpu_fft_batch_f64: log2n %d outside [1,24]", log2n);
+    if (direction != DSP_GPU_FORWARD && direction != DSP_GPU_INVERSE)
+        return fail(DSP_GPU_EINVAL, "dsp_gpu_fft_batch_f64: direction %d", direction);
+    if (bad_mem(mem)) return fail(DSP_GPU_EINVAL, "dsp_gpu_fft_batch_f64: mem %d", mem);
+    if (batch == 0) return DSP_GPU_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (mem == DSP_GPU_MEM_DEVICE)
+        return launch_fft_batch_f64(static_cast<const double *>(in), static_cast<double *>(out), log2n, batch, direction, s);
+    const size_t unit = (2 * sizeof(double)) << log2n;
+    return host_route(in, unit, unit * batch, out, unit, batch, s, [=](const void *din, void *dout, size_t, size_t count, void *) {
+        return launch_fft_batch_f64(static_cast<const double *>(din), static_cast<double *>(dout), log2n, count, direction, s);
+    });
+}
+
 int dsp_gpu_fft_batch_noalloc(const void *in, void *out, int log2n, size_t batch, int direction, void *stream) {
     if (!in || !out) return fail(DSP_GPU_EINVAL, "dsp_gpu_fft_batch_noalloc: null buffer");
     if (log2n < 1 || log2n > 21) return fail(DSP_GPU_EINVAL, "dsp_gpu_fft_batch_noalloc: log2n %d outside [1,21]", log2n);

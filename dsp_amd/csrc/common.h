@@ -90,6 +90,7 @@ void release_host_pipes(int dev);
 
 // ---- kernel launchers (device pointers, asynchronous on `s`) --------------------------
 int launch_fft_batch(const float2 *in, float2 *out, int log2n, size_t batch, int direction, hipStream_t s);
+int launch_fft_batch_f64(const double *in, double *out, int log2n, size_t batch, int direction, hipStream_t s);
 int launch_fft_batch_noalloc(const float2 *in, float2 *out, int log2n, size_t batch, int direction, hipStream_t s);
 size_t fft_noalloc_max_points();
 int launch_fft_real_batch(const float *in, size_t n_in, size_t in_stride, float2 *out, int log2n,

@@ -108,6 +108,22 @@ def fft0(x, inverse: bool = False, out=None):
     return out
 
 
+def fft0_f64(x, inverse: bool = False, out=None):
+    """The same in the reference's own sample type, std::complex<double> (fft.h:31-32): complex128 in and out, double
+    arithmetic, length 2^k with k in 1..24."""
+    x, px, mem = _prep(x, np.complex128, "complex128")
+    n = x.shape[-1]
+    log2n = int(n).bit_length() - 1
+    if n < 2 or (1 << log2n) != n:
+        raise capi.DspGpuError(capi.EINVAL, f"transform length {n} is not a power of two >= 2")
+    batch = int(np.prod(x.shape[:-1])) if x.ndim > 1 else 1
+    out = _out(out, x, tuple(x.shape), np.complex128, "complex128")
+    with _on_device(x):
+        capi.check(capi.lib().dsp_gpu_fft_batch_f64(px, _ptr(out), log2n, batch, capi.INVERSE if inverse else capi.FORWARD,
+                                                    mem, _stream_of(x)))
+    return out
+
+
 def fft(x, nf: int, inverse: bool = False, shift: bool = False):
     """Real-input wrapper dsp::fft (fft.h:57-83), optionally followed by dsp::shift (fft.h:85-94)."""
     x, px, mem = _prep(x, np.float32, "float32")

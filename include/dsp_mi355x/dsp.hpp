@@ -8,7 +8,7 @@
 // microseconds (dsp.h:47-79, recursive_filters.h:24-263).
 //
 //   reference                                         here (namespace dsp_mi355x)
-//   dsp::fft0<type>(in, out, log2n)      fft.h:31     fft0<type>(in, out, log2n, batch = 1)
+//   dsp::fft0<type>(in, out, log2n)      fft.h:31     fft0<type>(in, out, log2n, batch = 1)   complex<float> and complex<double>
 //   dsp::fft<It,CIt,type>(f, l, out, nf) fft.h:57     fft<type>(f, l, out, nf)
 //   dsp::shift(vector<complex>)          fft.h:85     shift(vector<complex<float>>)
 //   dsp::sinc<Inv>(cf, length, window)   dsp.h:47     sinc<Inv>(cf, length, window)
@@ -90,6 +90,13 @@ template <FFTType type = FFTType::FORWARD>
 void fft0(const std::complex<float> *in, std::complex<float> *out, int log2n, size_t batch = 1) {
     check(dsp_gpu_fft_batch(in, out, log2n, batch, type == FFTType::FORWARD ? DSP_GPU_FORWARD : DSP_GPU_INVERSE,
                             DSP_GPU_MEM_HOST, nullptr),
+          "fft0");
+}
+// The reference's own signature, fft.h:31-32: std::complex<double>, arithmetic in double on the GPU (log2n <= 24).
+template <FFTType type = FFTType::FORWARD>
+void fft0(const std::complex<double> *in, std::complex<double> *out, int log2n, size_t batch = 1) {
+    check(dsp_gpu_fft_batch_f64(in, out, log2n, batch, type == FFTType::FORWARD ? DSP_GPU_FORWARD : DSP_GPU_INVERSE,
+                                DSP_GPU_MEM_HOST, nullptr),
           "fft0");
 }
 // Same on device pointers, asynchronous on `stream` (a hipStream_t).

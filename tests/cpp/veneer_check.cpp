@@ -83,6 +83,13 @@ int run(const std::string &dir) {
         dump(dir + "/fft_fwd.c64", fwd.data(), fwd.size());
         dump(dir + "/fft_back.c64", back.data(), back.size());
     }
+    // the reference's own signature (fft.h:31-32): std::complex<double>, same input widened
+    {
+        auto in32 = slurp<std::complex<float>>(dir + "/fft_in.c64");
+        std::vector<std::complex<double>> in(in32.begin(), in32.end()), fwd(in.size());
+        fft0<FFTType::FORWARD>(in.data(), fwd.data(), 10, in.size() / 1024);
+        dump(dir + "/fft_fwd.c128", fwd.data(), fwd.size());
+    }
     // eval/recursive_filters/main.cpp:104-121: impulse at N/2 -> filter -> 1024-point fft
     {
         SampleBuffer<float> impulse(1024, 0.0f);
