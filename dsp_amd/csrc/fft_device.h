@@ -226,6 +226,52 @@ struct Dft<16, SIGN> {
     }
 };
 
+// multiply by exp(SIGN * 2 pi i * q / 32); q is a constant once the caller's loops are unrolled.  The constant is
+// materialised in a scalar register pair at the point of use (the empty volatile asm cannot be hoisted): left to
+// itself the compiler keeps every distinct constant live across a persistent loop and spills scalar registers.
+template <int SIGN>
+DSP_DEV c32 mul_w32(c32 a, int q) {
+    q &= 31;
+    if (q == 0) return a;
+    if (q == 8) return mul_i<SIGN>(a);
+    if (q == 16) return -a;
+    if (q == 24) return mul_i<-SIGN>(a);
+    c32 k = c32{cos64(2 * q), SIGN * sin64(2 * q)};
+    asm volatile("" : "+s"(k));
+    return cmul_k(a, k);
+}
+
+// 32 = 8 x 4: n = 4*n1 + n2, k = k1 + 8*k2.  Natural order in and out.
+template <int SIGN>
+struct Dft<32, SIGN> {
+    static DSP_DEV void run(c32 (&v)[32]) {
+#pragma unroll
+        for (int n2 = 0; n2 < 4; ++n2) {  // A[k1][n2] = sum_n1 v[4 n1 + n2] W8^{n1 k1}, left at v[4 k1 + n2]
+            c32 t[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) t[i] = v[4 * i + n2];
+            Dft<8, SIGN>::run(t);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[4 * i + n2] = t[i];
+        }
+#pragma unroll
+        for (int k1 = 1; k1 < 8; ++k1) {
+#pragma unroll
+            for (int n2 = 1; n2 < 4; ++n2) v[4 * k1 + n2] = mul_w32<SIGN>(v[4 * k1 + n2], n2 * k1);
+        }
+#pragma unroll
+        for (int k1 = 0; k1 < 8; ++k1) dft4<SIGN>(v[4 * k1], v[4 * k1 + 1], v[4 * k1 + 2], v[4 * k1 + 3]);
+        c32 o[32];  // X[k1 + 8 k2] sits at v[4 k1 + k2]: a renaming, no instruction
+#pragma unroll
+        for (int k1 = 0; k1 < 8; ++k1) {
+#pragma unroll
+            for (int k2 = 0; k2 < 4; ++k2) o[k1 + 8 * k2] = v[4 * k1 + k2];
+        }
+#pragma unroll
+        for (int i = 0; i < 32; ++i) v[i] = o[i];
+    }
+};
+
 // exp(SIGN * 2 pi i * num / 2^log2den), num < 2^24 exact in fp32; sincospif is accurate
 // to ~1 ulp, which keeps the transform well inside the 1e-5*log2(N) budget (the reference
 // builds its twiddles by a double-precision recurrence, fft.h:43-44,52).

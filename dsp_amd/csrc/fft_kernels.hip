@@ -244,8 +244,9 @@ __global__ __launch_bounds__((1 << LOG2N) / kPoints) void fft_big_kernel(const v
 
 // ---- 2^15 points in ONE pass through HBM -----------------------------------------------------------------------
 // 512 threads x 64 register-resident points; the complex image of the transform (256 KB) does not fit a CU's LDS, so the
-// points cross between passes one fp32 plane at a time (real parts, then imaginary parts) through a 136 KB image:
-// radix 16, 16, 16, 8 -- four passes, three exchanges of two planes each.  One workgroup per CU, persistent, XCD x owns
+// points cross between passes one fp32 plane at a time (real parts, then imaginary parts) through a 132 KB image:
+// radix 32, 32, 32 -- three passes, two exchanges of two planes each (the exchanges are what costs: 512 KB of LDS traffic
+// each; radix 16, 16, 16, 8 with three of them ran 7 % slower).  One workgroup per CU, persistent, XCD x owns
 // the contiguous range [x*chunk, (x+1)*chunk) of the batch.  Against the two-pass route (16 B + 16 B per point) this
 // is one read and one write of every point.
 // REAL_HALF: rows of 2^16 real samples ride the 2^15-point transform and the 2^16-bin spectrum is unfolded in the same
@@ -253,29 +254,30 @@ __global__ __launch_bounds__((1 << LOG2N) / kPoints) void fft_big_kernel(const v
 constexpr int kPlanePoints = 64;
 constexpr int kPlaneLog2N = 15;
 constexpr int kPlaneThreads = (1 << kPlaneLog2N) / kPlanePoints;                        // 512
-constexpr size_t kPlaneLdsBytes = ((1 << kPlaneLog2N) + (1 << kPlaneLog2N) / 16) * sizeof(float);  // 139,264
+constexpr size_t kPlaneLdsBytes = ((1 << kPlaneLog2N) + (1 << kPlaneLog2N) / 32) * sizeof(float);  // 135,168
+DSP_DEV int plane_padded(int i) { return i + (i >> 5); }  // one pad word per 32: the radix-32 scatter strides by 33 words
 
-// scatter the outputs of the pass (radix 16 after sub-length NS), gather r[m] = element lt + T m; one plane at a time
+// scatter the outputs of the pass (radix 32 after sub-length NS), gather r[m] = element lt + T m; one plane at a time
 template <int NS>
 DSP_DEV void plane_exchange(c32 (&r)[kPlanePoints], float *lds, int lt) {
-    constexpr int R = 16, T = kPlaneThreads, B = kPlanePoints / R;
-    static_assert(NS == 1 || NS % 16 == 0, "sub-length");
+    constexpr int R = 32, T = kPlaneThreads, B = kPlanePoints / R;
+    static_assert(NS == 1 || NS % 32 == 0, "sub-length");
 #pragma unroll
     for (int part = 0; part < 2; ++part) {
         __syncthreads();  // the image of the previous plane / exchange / transform has been read by everyone
 #pragma unroll
         for (int s = 0; s < B; ++s) {
             const int j = lt + T * s;
-            // padded(dest + u NS) is linear in u: 16 j + u -> 17 j + u (NS = 1), x + 16 k -> padded(x) + 17 k otherwise
-            float *w = lds + padded(stockham_dest<R, NS>(j, 0));
+            // plane_padded(dest + u NS) is linear in u: 32 j + u -> 33 j + u (NS = 1), x + 32 k -> plane_padded(x) + 33 k otherwise
+            float *w = lds + plane_padded(stockham_dest<R, NS>(j, 0));
 #pragma unroll
-            for (int u = 0; u < R; ++u) w[NS == 1 ? u : u * (NS + NS / 16)] = part ? r[s + u * B].y : r[s + u * B].x;
+            for (int u = 0; u < R; ++u) w[NS == 1 ? u : u * (NS + NS / 32)] = part ? r[s + u * B].y : r[s + u * B].x;
         }
         __syncthreads();
-        const float *g = lds + padded(lt);
+        const float *g = lds + plane_padded(lt);
 #pragma unroll
         for (int m = 0; m < kPlanePoints; ++m) {
-            const float v = g[m * (T + T / 16)];
+            const float v = g[m * (T + T / 32)];
             if (part) r[m].y = v;
             else r[m].x = v;
         }
@@ -317,13 +319,11 @@ __global__ __launch_bounds__(kPlaneThreads) void fft_plane_kernel(const void *__
 #pragma unroll
             for (int m = 0; m < P; ++m) r[m] = load_stream(src + lt + T * m);
         }
-        stockham_pass<16, 1, LOG2N, SIGN, P>(r, lt);
+        stockham_pass<32, 1, LOG2N, SIGN, P>(r, lt);
         plane_exchange<1>(r, plane_lds, lt);
-        stockham_pass<16, 16, LOG2N, SIGN, P>(r, lt);
-        plane_exchange<16>(r, plane_lds, lt);
-        stockham_pass<16, 256, LOG2N, SIGN, P>(r, lt);
-        plane_exchange<256>(r, plane_lds, lt);
-        stockham_pass<8, 4096, LOG2N, SIGN, P>(r, lt);
+        stockham_pass<32, 32, LOG2N, SIGN, P>(r, lt);
+        plane_exchange<32>(r, plane_lds, lt);
+        stockham_pass<32, 1024, LOG2N, SIGN, P>(r, lt);
         if constexpr (REAL_HALF) {
             // Z[k], k = lt + T m, in natural order through the image once more, a plane at a time: bin k needs Z[N - k].
             // With zc = conj Z[N - k]:  E = (Z + zc)/2, i O = (Z - zc)/2, X[k] = E + W_2N^k O, X[k + N] = E - W_2N^k O.
@@ -331,11 +331,11 @@ __global__ __launch_bounds__(kPlaneThreads) void fft_plane_kernel(const void *__
             // that they are not hoisted out of the persistent loop (64 + 64 address registers held across all passes).
             int lv = lt;
             asm volatile("" : "+v"(lv));
-            float *own = plane_lds + padded(lv);
+            float *own = plane_lds + plane_padded(lv);
             // N - k = (T - lt) + T (63 - m) for lt > 0; thread 0: T (64 - m), and bin 0 mirrors itself.
-            // padded(x + T j) = padded(x) + (T + T/16) j.
-            const float *mir = plane_lds + padded(T - lv);
-            constexpr int kRow = T + T / 16;
+            // plane_padded(x + T j) = plane_padded(x) + (T + T/32) j.
+            const float *mir = plane_lds + plane_padded(T - lv);
+            constexpr int kRow = T + T / 32;
             float dx[P];
             __syncthreads();
 #pragma unroll
