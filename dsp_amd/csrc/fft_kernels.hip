@@ -693,10 +693,17 @@ int dispatch_small(int log2n, const void *in, c32 *out, size_t batch, size_t n_i
     }
 }
 
+// DSP_GPU_REAL_SHORT_LAST=0 (A/B): the balanced factorisation for the half-length real-input route too
+bool real_half_short_last() {
+    const char *e = getenv("DSP_GPU_REAL_SHORT_LAST");
+    return !e || e[0] != '0';
+}
+
 int launch_column(int log2l, const c32 *in, c32 *out, const ColumnPlan &plan, size_t slabs, int direction,
                   hipStream_t s) {
     const int L = 1 << log2l;
-    const bool wide = log2l >= 7 && plan.B % (2 * kTile / L) == 0;  // 512 threads: twice the columns
+    // 512 threads: twice the columns.  The unfolding pass (mirrored half tiles) also for 64-point columns.
+    const bool wide = (log2l >= 7 || (log2l == 6 && plan.unfold)) && plan.B % (2 * kTile / L) == 0;
     const int C = (wide ? 2 : 1) * kTile / L;
     if (plan.B % C != 0) return fail(DSP_GPU_EINVAL, "column pass: inner extent %zu not a multiple of %d", plan.B, C);
     const size_t blocks = slabs * (plan.B / C);
@@ -710,7 +717,7 @@ int launch_column(int log2l, const c32 *in, c32 *out, const ColumnPlan &plan, si
     case K: DSP_LAUNCH(K, kThreads) break;
 #define DSP_CASE_WIDE(K) \
     case K: if (wide) { DSP_LAUNCH(K, 2 * kThreads) } else { DSP_LAUNCH(K, kThreads) } break;
-        DSP_CASE(4) DSP_CASE(5) DSP_CASE(6) DSP_CASE_WIDE(7) DSP_CASE_WIDE(8)
+        DSP_CASE(4) DSP_CASE(5) DSP_CASE_WIDE(6) DSP_CASE_WIDE(7) DSP_CASE_WIDE(8)
 #undef DSP_CASE
 #undef DSP_CASE_WIDE
 #undef DSP_LAUNCH
@@ -732,11 +739,23 @@ int launch_large(const c32 *in, c32 *out, int log2n, size_t batch, int direction
                  const float *real_in = nullptr, size_t real_n_in = 0, size_t real_stride = 0,
                  c32 *fixed_scratch = nullptr, int real_half = 0) {
     const size_t n = static_cast<size_t>(1) << log2n;
-    const int steps = log2n <= 16 ? 2 : (log2n <= 24 ? 3 : 4);
+    // (rows of 2^17 real samples: two passes would leave the unfolding one 256-point columns, 16 + 16 to a tile and
+    // 128-byte runs -- three passes with 512-byte runs are faster, 165 -> 183 GSamples/s)
+    const int steps = log2n <= 16 && !(real_half && log2n == 16 && real_half_short_last()) ? 2 : (log2n <= 24 ? 3 : 4);
     int lg[4] = {0, 0, 0, 0};
     for (int i = 0, left = log2n; i < steps; ++i) {
         lg[i] = (left + (steps - i) - 1) / (steps - i);
         left -= lg[i];
+    }
+    if (real_half && real_half_short_last() && lg[steps - 1] >= 7 && log2n - 6 <= 8 * (steps - 1)) {
+        // The unfolding last pass moves its tile as two mirrored halves, so its memory runs are half as long as a plain
+        // pass's: 128-point columns leave it 256-byte runs.  Give it 64-point columns (512-byte runs with the wide tile)
+        // where the earlier passes can take up the difference (2^22 real samples: 140 -> 164 GSamples/s).
+        lg[steps - 1] = 6;
+        for (int i = 0, left = log2n - 6; i + 1 < steps; ++i) {
+            lg[i] = (left + (steps - 1 - i) - 1) / (steps - 1 - i);
+            left -= lg[i];
+        }
     }
     c32 *scratch = fixed_scratch;
     if (!scratch) {

@@ -7,7 +7,7 @@ total = 1 << 28
 x = torch.randn(total, device="cuda")
 out = torch.empty(total, dtype=torch.complex64, device="cuda")
 import ctypes as C
-for log2n in (6, 8, 10, 12, 13, 14, 15, 16, 18, 20):
+for log2n in eval(os.environ.get("REAL_SIZES", "(6, 8, 10, 12, 13, 14, 15, 16, 17, 18, 20, 22, 23, 24)")):
     n = 1 << log2n
     xv = x.view(total // n, n)
     def run():
