@@ -34,6 +34,15 @@
 #include "common.h"
 
 namespace dspgpu {
+// Ablation switches for scripts/iir_scan_ablate.hip, which compiles this file with DSPGPU_SCAN_ABLATE defined and times the
+// scan kernel with phases switched off (1 = phase A, 2 = phase B, 4 = phase C).  In the library build they are
+// compile-time false and leave no trace in the kernels.
+#ifdef DSPGPU_SCAN_ABLATE
+__device__ int g_scan_ablate = 0;
+#define SCAN_ABLATED(bit) ((g_scan_ablate & (bit)) != 0)
+#else
+#define SCAN_ABLATED(bit) false
+#endif
 namespace {
 
 #define DSP_DEV __device__ __forceinline__
@@ -481,7 +490,8 @@ __global__ __launch_bounds__(kSt) void iir_scan_kernel(const float *__restrict__
         xh[i] = xh0[i];
         vh[i] = 0.0;
     }
-    if (MODE == SCAN_REDUCE || last_row) run_row4<P, kRow, false>(row, xh, vh, co);
+    if (SCAN_ABLATED(1)) {
+    } else if (MODE == SCAN_REDUCE || last_row) run_row4<P, kRow, false>(row, xh, vh, co);
     else run_row4<P, kRow, true>(row, xh, vh, co);
     SVec<P, WIDE> S;
     sv_zero<P, WIDE>(S);
@@ -519,7 +529,7 @@ __global__ __launch_bounds__(kSt) void iir_scan_kernel(const float *__restrict__
     // lanes of the wave with shuffles.  `levels` is the number of doubling levels whose matrix is not
     // negligible (host: ||A^(32*2^j)|| > 2^-60), so a fast-decaying filter stops early.
     const int lane = tid;
-    wave_scan<P, WIDE>(S, mats, levels < kLevels ? levels : kLevels, lane);
+    if (!SCAN_ABLATED(2)) wave_scan<P, WIDE>(S, mats, levels < kLevels ? levels : kLevels, lane);
     const SVec<P, WIDE> cw = carry;  // true state at the start of the tile
     if (MODE == SCAN_REDUCE) {
         if (tid == kSt - 1) sv_store<P, WIDE>(S, tile_z + (ch * ntiles + tile) * W);
@@ -548,7 +558,7 @@ __global__ __launch_bounds__(kSt) void iir_scan_kernel(const float *__restrict__
                 so[P + i] = vh[i];
             }
         }
-    } else if (g0 < n) {
+    } else if (g0 < n && !SCAN_ABLATED(4)) {
         // v[t] = v_zero_state[t] + sum_i hrow[t][i] * v[-1-i]: hrow[t] is the first row of A^(t+1) (host, from
         // the recursion run on unit states), uniform across lanes (scalar loads), no loop-carried dependency
 #pragma unroll
