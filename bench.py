@@ -269,7 +269,10 @@ def main():
         sys.exit("bench.py needs a GPU (the product path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # DSP_BENCH_INIT_DIST=1: also at world 1 (under torch.distributed.run --nproc-per-node 1), to rehearse the RCCL
+    # set-up, barrier and reductions of the N > 1 run on a one-GPU box
+    use_dist = world > 1 or bool(os.environ.get("DSP_BENCH_INIT_DIST"))
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
@@ -280,7 +283,7 @@ def main():
         SHARD = (rank, world)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     def measure(workload, steps, warmup):
@@ -361,7 +364,7 @@ def main():
                     rec["cpu_baseline"] = cpu_baseline(w, min(args.cpu_seconds / 4, 3.0))
                 line["secondary"].append(rec)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

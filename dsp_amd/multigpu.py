@@ -14,7 +14,7 @@ def shard_range(total: int, rank: int, world: int):
 def max_over_ranks(value: float, device=None, group=None) -> float:
     import torch
     import torch.distributed as dist
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_initialized():
         return float(value)
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
@@ -24,7 +24,7 @@ def max_over_ranks(value: float, device=None, group=None) -> float:
 def sum_over_ranks(value: float, device=None, group=None) -> float:
     import torch
     import torch.distributed as dist
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_initialized():
         return float(value)
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
