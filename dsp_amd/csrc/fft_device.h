@@ -119,12 +119,12 @@ constexpr float sin128(int q) { return cos128(q + 96); }  // sin(x) = cos(x - pi
 // exp(2 pi i s / P) for the register counts in use (P points per thread)
 template <int P>
 constexpr float cos_per_points(int s) {
-    static_assert(P == 16 || P == 64, "points per thread");
-    return P == 16 ? cos16(s) : cos64(s);
+    static_assert(P == 16 || P == 32 || P == 64, "points per thread");
+    return P == 16 ? cos16(s) : (P == 32 ? cos64(2 * s) : cos64(s));
 }
 template <int P>
 constexpr float sin_per_points(int s) {
-    return P == 16 ? sin16(s) : sin64(s);
+    return P == 16 ? sin16(s) : (P == 32 ? sin64(2 * s) : sin64(s));
 }
 
 // multiply by exp(SIGN * 2 pi i * Q / 16), Q a compile-time constant

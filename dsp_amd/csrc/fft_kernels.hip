@@ -157,28 +157,29 @@ __global__ __launch_bounds__(kThreads) void fft_lds_kernel(const void *__restric
 // with E / O the transforms of the even / odd samples, Z[k] = E[k] + i O[k] and, x being real, conj Z[N-k] = E[k] - i O[k];
 // X[k] = E[k] + W_2N^k O[k], X[k+N] = E[k] - W_2N^k O[k].  Half the butterflies and half the LDS of the full-length
 // transform, and rows of 2^15 samples still take one trip through HBM (4 B read + 8 B written per sample).
-template <int LOG2N, int SIGN, bool REAL_IN, bool SHIFTED, bool REAL_HALF = false>
-__global__ __launch_bounds__((1 << LOG2N) / kPoints) void fft_big_kernel(const void *__restrict__ in_, c32 *__restrict__ out,
+template <int LOG2N, int SIGN, bool REAL_IN, bool SHIFTED, bool REAL_HALF = false, int P = kPoints>
+__global__ __launch_bounds__((1 << LOG2N) / P) void fft_big_kernel(const void *__restrict__ in_, c32 *__restrict__ out,
                                                                          size_t batch, size_t chunk, size_t n_in,
                                                                          size_t in_stride) {
     constexpr int N = 1 << LOG2N;
-    constexpr int T = N / kPoints;  // threads
+    constexpr int T = N / P;  // threads
+    auto pad = [](int i) { return P == 32 ? padded32(i) : padded(i); };
     extern __shared__ __attribute__((aligned(16))) c32 big_lds[];
     const int lt = threadIdx.x;
     const size_t per_xcd = gridDim.x >> 3;
     const size_t lo = static_cast<size_t>(blockIdx.x & 7u) * chunk, hi = lo + chunk < batch ? lo + chunk : batch;
     size_t t = lo + (blockIdx.x >> 3);
     if (t >= hi) return;
-    auto fetch = [&](c32 (&v)[kPoints], size_t row) {
+    auto fetch = [&](c32 (&v)[P], size_t row) {
         if constexpr (REAL_HALF) {
             const float *src = static_cast<const float *>(in_) + row * in_stride;
             const bool pairs = (in_stride & 1) == 0 && (reinterpret_cast<uintptr_t>(in_) & 7) == 0;
             if (pairs && n_in >= static_cast<size_t>(2 * N)) {  // no padding, 8-byte aligned rows: the row IS the complex input
 #pragma unroll
-                for (int m = 0; m < kPoints; ++m) v[m] = load_stream(reinterpret_cast<const c32 *>(src) + lt + T * m);
+                for (int m = 0; m < P; ++m) v[m] = load_stream(reinterpret_cast<const c32 *>(src) + lt + T * m);
             } else {
 #pragma unroll
-                for (int m = 0; m < kPoints; ++m) {
+                for (int m = 0; m < P; ++m) {
                     const size_t i = 2 * static_cast<size_t>(lt + T * m);
                     v[m] = mk(i < n_in ? src[i] : 0.0f, i + 1 < n_in ? src[i + 1] : 0.0f);
                 }
@@ -186,41 +187,42 @@ __global__ __launch_bounds__((1 << LOG2N) / kPoints) void fft_big_kernel(const v
         } else if constexpr (REAL_IN) {  // rows of real samples, zero padded (fft.h:65-74)
             const float *src = static_cast<const float *>(in_) + row * in_stride;
 #pragma unroll
-            for (int m = 0; m < kPoints; ++m) {
+            for (int m = 0; m < P; ++m) {
                 const size_t i = lt + T * m;
                 v[m] = mk(i < n_in ? src[i] : 0.0f, 0.0f);
             }
         } else {
             const c32 *src = static_cast<const c32 *>(in_) + row * N;
 #pragma unroll
-            for (int m = 0; m < kPoints; ++m) v[m] = load_stream(src + lt + T * m);
+            for (int m = 0; m < P; ++m) v[m] = load_stream(src + lt + T * m);
         }
     };
-    c32 nxt[kPoints];
+    c32 nxt[P];
     fetch(nxt, t);
     for (; t < hi; t += per_xcd) {
-        c32 r[kPoints];
+        c32 r[P];
 #pragma unroll
-        for (int m = 0; m < kPoints; ++m) r[m] = nxt[m];
+        for (int m = 0; m < P; ++m) r[m] = nxt[m];
         if (t + per_xcd < hi) fetch(nxt, t + per_xcd);
-        fft_passes<LOG2N, SIGN>(r, big_lds, lt, 0);
+        if constexpr (P == 32) fft_passes32<LOG2N, SIGN>(r, big_lds, lt);
+        else fft_passes<LOG2N, SIGN>(r, big_lds, lt, 0);
         __syncthreads();  // the last image has been read before the next transform's first exchange
         if constexpr (REAL_HALF) {
             // Z in natural order through the image once more: bin k needs its mirror N - k
 #pragma unroll
-            for (int m = 0; m < kPoints; ++m) big_lds[padded(lt + T * m)] = r[m];
+            for (int m = 0; m < P; ++m) big_lds[pad(lt + T * m)] = r[m];
             __syncthreads();
             // W_2N^k, k = lt + T m:  W^lt (W^T)^m -- two sincos and a product tree
             const c32 w0 = unit_root<SIGN>(static_cast<unsigned>(lt), LOG2N + 1);
-            c32 pw[kPoints];
+            c32 pw[P];
             pw[1] = unit_root<SIGN>(static_cast<unsigned>(T), LOG2N + 1);
 #pragma unroll
-            for (int m = 2; m < kPoints; ++m) pw[m] = cmul(pw[m >> 1], pw[m - (m >> 1)]);
+            for (int m = 2; m < P; ++m) pw[m] = cmul(pw[m >> 1], pw[m - (m >> 1)]);
             c32 *row = out + t * (2 * N);
 #pragma unroll
-            for (int m = 0; m < kPoints; ++m) {
+            for (int m = 0; m < P; ++m) {
                 const int k = lt + T * m;
-                const c32 zp = big_lds[padded((N - k) & (N - 1))];
+                const c32 zp = big_lds[pad((N - k) & (N - 1))];
                 const c32 zc = mk(zp.x, -zp.y);                       // conj Z[N - k] = E - i O
                 const c32 e = (r[m] + zc) * 0.5f;
                 const c32 d = (r[m] - zc) * 0.5f;                      // i O
@@ -234,7 +236,7 @@ __global__ __launch_bounds__((1 << LOG2N) / kPoints) void fft_big_kernel(const v
             continue;
         }
 #pragma unroll
-        for (int m = 0; m < kPoints; ++m) {
+        for (int m = 0; m < P; ++m) {
             int k = lt + T * m;
             if constexpr (SHIFTED) k = (k + N / 2) & (N - 1);  // dsp::shift fused (fft.h:85-94)
             store_stream(out + t * N + k, r[m]);
@@ -795,19 +797,34 @@ int launch_large(const c32 *in, c32 *out, int log2n, size_t batch, int direction
 }  // namespace
 
 namespace {
-template <int LOG2N, bool REAL_IN, bool SHIFTED, bool REAL_HALF = false>
-int launch_big(const void *in, c32 *out, size_t batch, size_t n_in, size_t in_stride, int direction, hipStream_t s) {
+// DSP_GPU_BIG_P32=0 (A/B): 16 points per thread and radix-16 passes (three exchanges) instead of 32 and two
+bool big_p32() {
+    const char *e = getenv("DSP_GPU_BIG_P32");
+    return !e || e[0] != '0';
+}
+
+template <int LOG2N, bool REAL_IN, bool SHIFTED, bool REAL_HALF, int P>
+int launch_big_p(const void *in, c32 *out, size_t batch, size_t n_in, size_t in_stride, int direction, hipStream_t s) {
     constexpr int N = 1 << LOG2N;
-    const size_t lds_bytes = static_cast<size_t>(N + N / 16) * sizeof(c32);
+    const size_t lds_bytes = static_cast<size_t>(N + N / P) * sizeof(c32);
     const size_t chunk = (batch + 7) / 8;
     const size_t per_xcd = std::min<size_t>(chunk, 32 * (LOG2N == 13 ? 2 : 1));  // resident workgroups per XCD
-    auto kf = fft_big_kernel<LOG2N, +1, REAL_IN, SHIFTED, REAL_HALF>;
-    auto ki = fft_big_kernel<LOG2N, -1, REAL_IN, SHIFTED, REAL_HALF>;
+    auto kf = fft_big_kernel<LOG2N, +1, REAL_IN, SHIFTED, REAL_HALF, P>;
+    auto ki = fft_big_kernel<LOG2N, -1, REAL_IN, SHIFTED, REAL_HALF, P>;
     auto kern = direction == DSP_GPU_FORWARD ? kf : ki;
     if (int rc = allow_full_lds(reinterpret_cast<const void *>(kern))) return rc;
-    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(8 * per_xcd)), dim3(N / kPoints), lds_bytes, s, in, out, batch, chunk,
+    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(8 * per_xcd)), dim3(N / P), lds_bytes, s, in, out, batch, chunk,
                        n_in, in_stride);
     return check_launch("fft_big_kernel");
+}
+
+template <int LOG2N, bool REAL_IN, bool SHIFTED, bool REAL_HALF = false>
+int launch_big(const void *in, c32 *out, size_t batch, size_t n_in, size_t in_stride, int direction, hipStream_t s) {
+    // 32 points per thread where it was measured faster: complex 2^14 (309 -> 341 GSamples/s).  2^13 lost 2 % with it
+    // (two workgroups per CU already hide its exchanges) and the real-input forms lost their registers to the unfold.
+    if constexpr (LOG2N == 14 && !REAL_IN)
+        if (big_p32()) return launch_big_p<LOG2N, REAL_IN, SHIFTED, REAL_HALF, 32>(in, out, batch, n_in, in_stride, direction, s);
+    return launch_big_p<LOG2N, REAL_IN, SHIFTED, REAL_HALF, 16>(in, out, batch, n_in, in_stride, direction, s);
 }
 }  // namespace
 
@@ -838,7 +855,7 @@ int launch_fft_batch(const float2 *in_f2, float2 *out_f2, int log2n, size_t batc
     if (batch == 0) return DSP_GPU_OK;
     if (log2n <= 12) return dispatch_small<false, false>(log2n, in, out, batch, 0, 0, direction, s);
     if (log2n == 13) return launch_big<13, false, false>(in, out, batch, 0, 0, direction, s);  // one HBM pass: 338 against 187 GSamples/s
-    if (log2n == 14) return launch_big<14, false, false>(in, out, batch, 0, 0, direction, s);  //               317 against 190
+    if (log2n == 14) return launch_big<14, false, false>(in, out, batch, 0, 0, direction, s);  //               341 against 190
     if (log2n == 15 && plane_route()) return launch_plane<false, false>(in, out, batch, 0, 0, direction, s);
     return launch_large(in, out, log2n, batch, direction, s);
 }

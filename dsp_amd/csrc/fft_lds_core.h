@@ -70,4 +70,41 @@ DSP_DEV void fft_passes(c32 (&r)[kPoints], c32 *lds, int lt, int base) {
     }
 }
 
+// ---- the same with 32 points per thread (fft_big_kernel: 2^13 / 2^14 points in one workgroup) -------------------------
+// Radix 32 first: 2^14 = 32 * 32 * 16 and 2^13 = 32 * 16 * 16 take two exchanges where radix 16 takes three, and an
+// exchange of the whole transform through LDS is what these kernels pay most for.  The image is padded by one element
+// per 32 so that the radix-32 scatter strides by 33 elements.
+DSP_DEV int padded32(int i) { return i + (i >> 5); }
+
+template <int R, int NS, int LOG2N>
+DSP_DEV void lds_exchange32(c32 (&r)[32], c32 *lds, int lt) {
+    constexpr int P = 32, T = (1 << LOG2N) / P, B = P / R;
+    static_assert(T % 32 == 0 && ((NS == 1 && R == 32) || NS % 32 == 0), "exchange shape");
+#pragma unroll
+    for (int s = 0; s < B; ++s) {
+        const int j = lt + T * s;
+        // padded32(dest + u NS) is linear in u: 32 j + u -> 33 j + u (NS = 1), x + 32 k -> padded32(x) + 33 k otherwise
+        c32 *w = lds + padded32(stockham_dest<R, NS>(j, 0));
+#pragma unroll
+        for (int u = 0; u < R; ++u) w[NS == 1 ? u : u * (NS + NS / 32)] = r[s + u * B];
+    }
+    __syncthreads();
+    const c32 *g = lds + padded32(lt);
+#pragma unroll
+    for (int m = 0; m < P; ++m) r[m] = g[m * (T + T / 32)];
+}
+
+// In: r[m] = x[lt + T*m], T = N/32.  Out: r[m] = X[lt + T*m].  LOG2N = 13 (32 * 16 * 16) or 14 (32 * 32 * 16).
+template <int LOG2N, int SIGN>
+DSP_DEV void fft_passes32(c32 (&r)[32], c32 *lds, int lt) {
+    static_assert(LOG2N == 13 || LOG2N == 14, "size");
+    constexpr int R1 = LOG2N == 14 ? 32 : 16;
+    stockham_pass<32, 1, LOG2N, SIGN, 32>(r, lt);
+    lds_exchange32<32, 1, LOG2N>(r, lds, lt);
+    stockham_pass<R1, 32, LOG2N, SIGN, 32>(r, lt);
+    __syncthreads();  // every thread has finished reading the image of exchange 1
+    lds_exchange32<R1, 32, LOG2N>(r, lds, lt);
+    stockham_pass<16, 32 * R1, LOG2N, SIGN, 32>(r, lt);
+}
+
 }  // namespace dspgpu
