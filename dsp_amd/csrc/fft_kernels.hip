@@ -178,19 +178,28 @@ __global__ __launch_bounds__((1 << LOG2N) / P) void fft_big_kernel(const void *_
 #pragma unroll
                 for (int m = 0; m < P; ++m) v[m] = load_stream(reinterpret_cast<const c32 *>(src) + lt + T * m);
             } else {
+                // zero padding (fft.h:65-74) by the hardware: buffer loads of a descriptor that ends with the row return 0
+                // beyond it -- no branch around any load, no lane masks
+                const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(src), 0,
+                                                                    static_cast<int>(n_in < 2 * static_cast<size_t>(N) ? n_in : 2 * N) * 4, 0x00020000);
+                int lo8 = 8 * lt;  // laundered: the loop-invariant offsets are not worth registers held across the persistent loop
+                asm volatile("" : "+v"(lo8));
 #pragma unroll
                 for (int m = 0; m < P; ++m) {
-                    const size_t i = 2 * static_cast<size_t>(lt + T * m);
-                    v[m] = mk(i < n_in ? src[i] : 0.0f, i + 1 < n_in ? src[i + 1] : 0.0f);
+                    const int off = lo8 + 8 * T * m;
+                    v[m] = mk(__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, off, 0, 0)),
+                              __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, off + 4, 0, 0)));
                 }
             }
-        } else if constexpr (REAL_IN) {  // rows of real samples, zero padded (fft.h:65-74)
+        } else if constexpr (REAL_IN) {  // rows of real samples, zero padded (fft.h:65-74) by the descriptor's bounds check
             const float *src = static_cast<const float *>(in_) + row * in_stride;
+            const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(src), 0,
+                                                                static_cast<int>(n_in < static_cast<size_t>(N) ? n_in : N) * 4, 0x00020000);
+            int lo4 = 4 * lt;
+            asm volatile("" : "+v"(lo4));
 #pragma unroll
-            for (int m = 0; m < P; ++m) {
-                const size_t i = lt + T * m;
-                v[m] = mk(i < n_in ? src[i] : 0.0f, 0.0f);
-            }
+            for (int m = 0; m < P; ++m)
+                v[m] = mk(__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, lo4 + 4 * T * m, 0, 0)), 0.0f);
         } else {
             const c32 *src = static_cast<const c32 *>(in_) + row * N;
 #pragma unroll
@@ -820,9 +829,9 @@ int launch_big_p(const void *in, c32 *out, size_t batch, size_t n_in, size_t in_
 
 template <int LOG2N, bool REAL_IN, bool SHIFTED, bool REAL_HALF = false>
 int launch_big(const void *in, c32 *out, size_t batch, size_t n_in, size_t in_stride, int direction, hipStream_t s) {
-    // 32 points per thread where it was measured faster: complex 2^14 (309 -> 341 GSamples/s).  2^13 lost 2 % with it
-    // (two workgroups per CU already hide its exchanges) and the real-input forms lost their registers to the unfold.
-    if constexpr (LOG2N == 14 && !REAL_IN)
+    // 32 points per thread where it was measured faster: 2^14 points (complex 309 -> 341 GSamples/s, rows of 2^15 real
+    // samples 430 -> 441).  2^13 lost 2 % with it (two workgroups per CU already hide its exchanges).
+    if constexpr (LOG2N == 14)
         if (big_p32()) return launch_big_p<LOG2N, REAL_IN, SHIFTED, REAL_HALF, 32>(in, out, batch, n_in, in_stride, direction, s);
     return launch_big_p<LOG2N, REAL_IN, SHIFTED, REAL_HALF, 16>(in, out, batch, n_in, in_stride, direction, s);
 }
