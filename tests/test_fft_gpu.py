@@ -321,3 +321,36 @@ def test_real_65536_single_pass_equals_other_routes(ops, dev, orc, n_in, shift, 
     # the other direction of a real row is the conjugate spectrum
     den = torch.linalg.vector_norm(got.view(torch.float32).double())
     assert float(torch.linalg.vector_norm((inv - got.conj()).view(torch.float32).double()) / den) <= budget(16)
+
+
+def test_random_shapes_against_numpy(ops, dev):
+    """A seeded sweep over the dispatch table -- every kernel family (tiny, tile, single-workgroup 2^13 / 2^14 / 2^15,
+    multi-pass; real rows full- and half-length), odd batches, zero padding, shift, both directions, in place --
+    against numpy's FFT as an independent check (FORWARD = e^{+i} = N * ifft, nothing normalises)."""
+    import torch
+    rng = np.random.default_rng(20260)
+    for case in range(60):
+        log2n = int(rng.integers(1, 19))
+        n = 1 << log2n
+        batch = int(rng.integers(1, max(2, min(40, (1 << 21) // n) + 1)))
+        inverse = bool(rng.integers(0, 2))
+        if case % 2 == 0:  # complex
+            x = (rng.standard_normal((batch, n)) + 1j * rng.standard_normal((batch, n))).astype(np.complex64)
+            want = np.fft.fft(x.astype(np.complex128), axis=-1) if inverse else np.fft.ifft(x.astype(np.complex128), axis=-1) * n
+            xd = torch.from_numpy(x).to(dev)
+            got = ops.fft0(xd, inverse=inverse)
+            assert rel_l2(got.cpu().numpy(), want) <= budget(log2n), ("complex", log2n, batch, inverse)
+            buf = xd.clone()
+            ops.fft0(buf, inverse=inverse, out=buf)
+            assert torch.equal(buf, got), ("in place", log2n, batch, inverse)
+        else:  # real rows, zero padded to n, optionally shifted
+            n_in = int(rng.integers(1, n + 1)) if rng.integers(0, 3) else n
+            shift = bool(rng.integers(0, 2))
+            x = rng.standard_normal((batch, n_in)).astype(np.float32)
+            padded = np.zeros((batch, n))
+            padded[:, :n_in] = x
+            want = np.fft.fft(padded, axis=-1) if inverse else np.fft.ifft(padded, axis=-1) * n
+            if shift:
+                want = np.roll(want, n // 2, axis=-1)
+            got = ops.fft(torch.from_numpy(x).to(dev), n, inverse=inverse, shift=shift).cpu().numpy()
+            assert rel_l2(got, want) <= budget(log2n), ("real", log2n, batch, n_in, inverse, shift)
