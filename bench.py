@@ -37,7 +37,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="fft",
-                    choices=["fft", "fir_direct", "fir_direct_valu", "fir_os", "iir_batch", "iir_scan", "mavg", "fft_dist"])
+                    choices=["fft", "fir_direct", "fir_direct_valu", "fir_os", "iir_batch", "iir_scan", "mavg", "fft_dist",
+                             "fft_32k", "fft_real_64k", "fft_f64"])
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: every GPU gets the full per-GPU batch; strong: the one-GPU batch is channel-sharded")
     ap.add_argument("--dist-exchange", default="torch", choices=["torch", "rccl"],
@@ -80,6 +81,31 @@ def make_fft(torch, dev, ops, rank):
                         "batch": batch, "n": n, "sharding": "channels, no collective"},
                 bound="hbm", alg_per_unit=16.0, alg_unit="bytes/sample (8 B read + 8 B write)",
                 kernel="fft_lds_kernel<12>")
+    return step, batch * n, meta
+
+
+def make_fft_other(torch, dev, ops, rank, which):
+    """Not BASELINE configurations: the round-2 kernels that have no bench line of their own otherwise (profiles/)."""
+    g = torch.Generator(device=dev).manual_seed(555 + rank)
+    if which == "fft_32k":  # fft_plane_kernel: 2^15 points in one HBM pass
+        batch, n = _share(8192), 1 << 15
+        x = torch.view_as_complex(torch.randn(batch, n, 2, device=dev, generator=g))
+        out = torch.empty_like(x)
+        step = lambda: ops.fft0(x, False, out=out)  # noqa: E731
+        per, kernel, wl, dtype = 16.0, "fft_plane_kernel", "8,192 x 32,768-point complex fp32 FFT", "f32"
+    elif which == "fft_real_64k":  # the dsp::fft wrapper on rows of 2^16 samples (eval/modulation/helper.h:43's size)
+        batch, n = _share(4096), 1 << 16
+        x = torch.randn(batch, n, device=dev, generator=g)
+        step = lambda: ops.fft(x, n)  # noqa: E731  (allocates its output like the reference's wrapper does)
+        per, kernel, wl, dtype = 12.0, "fft_plane_kernel<REAL_HALF>", "4,096 rows of 65,536 real fp32 samples -> 65,536-bin spectra", "f32"
+    else:  # the reference's own sample type
+        batch, n = _share(16384), 4096
+        x = torch.view_as_complex(torch.randn(batch, n, 2, device=dev, generator=g, dtype=torch.float64))
+        out = torch.empty_like(x)
+        step = lambda: ops.fft0_f64(x, False, out=out)  # noqa: E731
+        per, kernel, wl, dtype = 32.0, "fft64_tile_kernel<12>", "16,384 x 4096-point complex DOUBLE FFT", "f64"
+    meta = dict(metric=f"{which}_throughput", unit="GSamples/s", dtype=dtype, bound="hbm", alg_per_unit=per,
+                alg_unit="bytes/sample", kernel=kernel, config={"workload": wl + " (FORWARD), per GPU", "batch": batch, "n": n})
     return step, batch * n, meta
 
 
@@ -292,6 +318,8 @@ def main():
             step, units, meta = make_fft_dist(torch, dev, world, rank, args.dist_exchange, args.dist_serial)
         elif workload == "fft":
             step, units, meta = make_fft(torch, dev, ops, rank)
+        elif workload in ("fft_32k", "fft_real_64k", "fft_f64"):
+            step, units, meta = make_fft_other(torch, dev, ops, rank, workload)
         elif workload in ("fir_direct", "fir_direct_valu", "fir_os"):
             step, units, meta = make_fir(torch, dev, ops, rank, {"fir_direct": "direct", "fir_direct_valu": "direct_valu",
                                                                  "fir_os": "overlap_save"}[workload])
@@ -349,7 +377,7 @@ def main():
                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": main_rec["ms_per_step"],
                 "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": main_rec["dtype"],
                 "data": "synthetic", "config": main_rec["config"], "roofline": main_rec["roofline"]}
-        cpu = world == 1 and not args.no_cpu_baseline
+        cpu = world == 1 and not args.no_cpu_baseline and args.workload not in ("fft_32k", "fft_real_64k", "fft_f64")
         if cpu:
             line["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_seconds)
             if args.cpu_threads > 1:  # reported beside it, never the target (the roofline fraction is)
