@@ -602,7 +602,10 @@ __global__ __launch_bounds__(kOsWaveThreads) void fir_os_wave_kernel(
         OSW_ROW16(nb, 0, b0); OSW_ROW16(nb, 1, b1); OSW_ROW16(nb, 2, b2); OSW_ROW16(nb, 3, b3);
     };
     // the same loads in 32 instalments of four (instalment k: rows 4k' .. 4k'+3 of block a for k < 16, of block b after)
+    // (the first 4 * I0 rows of block b are the last 4 * I0 rows of block a -- a plain pair is two consecutive blocks of one
+    // channel, hop = 4096 - 256 * I0 samples = whole rows -- and sit in the same lanes: they are not loaded a second time)
     auto prefetch_part = [&](const Pair &p, int k) {
+        if (k >= 16 && k < 16 + I0) return;
 #define OSW_PART(K)                                                                                       \
     case K: {                                                                                            \
         const float *base = x + ((K) < 16 ? p.oa : p.ob) + lane + 256 * ((K) & 15);                       \
@@ -637,7 +640,7 @@ __global__ __launch_bounds__(kOsWaveThreads) void fir_os_wave_kernel(
         OSW_TIE16(nb, 0); OSW_TIE16(nb, 1); OSW_TIE16(nb, 2); OSW_TIE16(nb, 3);
         c32 r[P];
 #pragma unroll
-        for (int m = 0; m < P; ++m) r[m] = mk(na[m], nb[m]);
+        for (int m = 0; m < P; ++m) r[m] = mk(na[m], m < 4 * I0 ? na[m + P - 4 * I0] : nb[m]);
         asm volatile("" ::: "memory");  // the prefetch below overwrites na/nb: keep it behind the copies above
         do nxt = locate(t += waves_per_xcd);
         while (nxt.valid && !nxt.plain);
