@@ -22,9 +22,10 @@
 //                      Across tiles either (REDUCE -> iir_carry_kernel -> APPLY: exact carries,
 //                      12 B/sample) or (FUSED: tiles overlap by W warm-up samples, chosen on the
 //                      host so that ||A^W|| <= 2^-44, i.e. the truncated history is below double
-//                      rounding; 8 B/sample + 4 B * W/(T-W)).  Workgroups are persistent and prefetch.
+//                      rounding; 8 B/sample + 4 B * W/(T-W)).  One workgroup per tile.
 //   iir_carry_kernel   scan of the per-tile end states (one workgroup per channel).
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -254,7 +255,6 @@ constexpr int kTile = kSt * kRow;   // 4096 samples per workgroup (measured: 32-
 constexpr int kLevels = 6;          // log2(kSt)
 constexpr int kCt = 256;            // threads of the tile-carry kernel
 constexpr int kCtLevels = 8;        // log2(kCt)
-constexpr unsigned kScanWgsPerCu = 8;  // resident workgroups (waves) per CU: 17.5 KB of LDS each (8 and 16: 560 GSamples/s, 9: 452)
 
 enum ScanMode { SCAN_REDUCE = 0, SCAN_APPLY = 1, SCAN_FUSED = 2 };
 
@@ -889,9 +889,18 @@ int scan_launch(const float *x, float *y, size_t channels, size_t n, const IirCo
         }
     }
 
-    // persistent: at most kScanWgsPerCu workgroups per CU of an XCD (32 CUs), fewer when there are fewer tiles
-    const dim3 grid(ntiles >= 64u ? 8u * std::min((ntiles + 7u) / 8u, 32u * kScanWgsPerCu) : ntiles,
-                    static_cast<unsigned>(channels));
+    // One workgroup (= one wave) per tile, XCD x taking the contiguous eighth [x*chunk, (x+1)*chunk) of a channel's tiles.
+    // Until round 2 the grid was persistent (8 workgroups per CU, each prefetching its next tile while it
+    // scanned the current one); plain copies showed that persistent grid-stride streaming is the slowest way to move
+    // data on this chip (profiles/r02_copy_ceiling.txt: 5.3-5.7 TB/s against 5.9-6.5 for one tile per workgroup: what
+    // counts is how little a CU keeps in flight), and the scan followed: 0.439 -> 0.409 ms on C4b, same box.  The
+    // kernel's loop still takes any grid (DSP_GPU_IIR_SCAN_WGS_PER_CU=8 restores the persistent launch for A/B).
+    static const unsigned wgs_per_cu = [] {
+        const char *e = getenv("DSP_GPU_IIR_SCAN_WGS_PER_CU");
+        return e && atoi(e) > 0 ? static_cast<unsigned>(atoi(e)) : 0u;
+    }();
+    const unsigned per_xcd = wgs_per_cu ? std::min((ntiles + 7u) / 8u, 32u * wgs_per_cu) : (ntiles + 7u) / 8u;
+    const dim3 grid(ntiles >= 64u ? 8u * per_xcd : ntiles, static_cast<unsigned>(channels));
     if (fused) {
         hipLaunchKernelGGL((iir_scan_kernel<P, SCAN_FUSED, ALIGNED, WIDE>), grid, dim3(kSt), 0, s, x, y, n, co, d_table,
                            state_in, state, nullptr, nullptr, ntiles, warm, levels, d_table + 18 * ms, 0);
