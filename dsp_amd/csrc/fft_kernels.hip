@@ -817,7 +817,11 @@ int launch_big_p(const void *in, c32 *out, size_t batch, size_t n_in, size_t in_
     constexpr int N = 1 << LOG2N;
     const size_t lds_bytes = static_cast<size_t>(N + N / P) * sizeof(c32);
     const size_t chunk = (batch + 7) / 8;
-    const size_t per_xcd = std::min<size_t>(chunk, 32 * (LOG2N == 13 ? 2 : 1));  // resident workgroups per XCD
+    // Resident workgroups per XCD, each walking its share of the batch with the next transform prefetched -- except complex
+    // 2^13, which runs one workgroup per transform: 307 -> 336 GSamples/s (A/B on one box; plain copies stream slowest from
+    // persistent grids, profiles/r02_copy_ceiling.txt).  The others lost 3-10 % that way: with one workgroup per CU, or
+    // the unfold's extra LDS phase, the prefetch is what hides their loads.
+    const size_t per_xcd = (LOG2N == 13 && !REAL_IN) ? chunk : std::min<size_t>(chunk, 32 * (LOG2N == 13 ? 2 : 1));
     auto kf = fft_big_kernel<LOG2N, +1, REAL_IN, SHIFTED, REAL_HALF, P>;
     auto ki = fft_big_kernel<LOG2N, -1, REAL_IN, SHIFTED, REAL_HALF, P>;
     auto kern = direction == DSP_GPU_FORWARD ? kf : ki;
@@ -841,7 +845,7 @@ namespace {
 template <bool REAL_HALF, bool SHIFTED>
 int launch_plane(const void *in, c32 *out, size_t batch, size_t n_in, size_t in_stride, int direction, hipStream_t s) {
     const size_t chunk = (batch + 7) / 8;
-    const size_t per_xcd = std::min<size_t>(chunk, 32);  // one resident workgroup per CU
+    const size_t per_xcd = std::min<size_t>(chunk, 32);  // one resident workgroup per CU (one workgroup per transform: no gain)
     auto kf = fft_plane_kernel<+1, REAL_HALF, SHIFTED>;
     auto ki = fft_plane_kernel<-1, REAL_HALF, SHIFTED>;
     auto kern = direction == DSP_GPU_FORWARD ? kf : ki;
