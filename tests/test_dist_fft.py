@@ -510,3 +510,41 @@ def test_exchange_callback_exception_propagates(dev):
     with pytest.raises(Boom):
         plan.run(x)
     plan.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fail_at", [0, 4, 7, 11])
+def test_pipelined_exchange_failure_leaves_the_plan_usable(orc, dev, fail_at):
+    """An exchange that fails in the middle of the pipelined schedule (world 1, twelve exchange calls) must fail the
+    transform with its code, leave nothing that hangs the streams, and the same plan must then transform correctly."""
+    import ctypes as C
+    import torch
+    from dsp_amd import capi, dist_fft
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+    log2n = 24
+    x = _signal(log2n, seed=7 + log2n)
+    calls = {"n": 0, "fail": fail_at}
+
+    def exchange(send, recv, nbytes, world, stream):
+        k = calls["n"]
+        calls["n"] += 1
+        if k == calls["fail"]:
+            return capi.EINVAL
+        return 0 if hip.hipMemcpyAsync(recv, send, nbytes * world, 3, stream) == 0 else capi.EHIP
+
+    plan = dist_fft.NativePlan(log2n, 0, 1, exchange=exchange)
+    try:
+        assert plan.exchanges() == 12
+        xd = torch.from_numpy(x).to(dev)
+        with pytest.raises(capi.DspGpuError):
+            plan.run(xd)
+        torch.cuda.synchronize()
+        assert calls["n"] == fail_at + 1  # nothing was exchanged after the failure
+        calls["n"], calls["fail"] = 0, -1
+        out = plan.run(xd).cpu().numpy()
+        assert calls["n"] == 12
+        assert rel_l2(out, _oracle_spectrum(orc, x, log2n, False)) <= 1e-5 * log2n
+    finally:
+        torch.cuda.synchronize()
+        plan.close()
