@@ -821,7 +821,7 @@ int launch_big_p(const void *in, c32 *out, size_t batch, size_t n_in, size_t in_
     // 2^13, which runs one workgroup per transform: 307 -> 336 GSamples/s (A/B on one box; plain copies stream slowest from
     // persistent grids, profiles/r02_copy_ceiling.txt).  The others lost 3-10 % that way: with one workgroup per CU, or
     // the unfold's extra LDS phase, the prefetch is what hides their loads.
-    const size_t per_xcd = (LOG2N == 13 && !REAL_IN) ? chunk : std::min<size_t>(chunk, 32 * (LOG2N == 13 ? 2 : 1));
+    const size_t per_xcd = (LOG2N == 13 && !REAL_IN) ? chunk : std::min<size_t>(chunk, 32 * (LOG2N == 12 ? 4 : (LOG2N == 13 ? 2 : 1)));
     auto kf = fft_big_kernel<LOG2N, +1, REAL_IN, SHIFTED, REAL_HALF, P>;
     auto ki = fft_big_kernel<LOG2N, -1, REAL_IN, SHIFTED, REAL_HALF, P>;
     auto kern = direction == DSP_GPU_FORWARD ? kf : ki;
@@ -990,7 +990,7 @@ int launch_fft_rows_exchange(const float2 *in_f2, float2 *out_f2, int log2n2, si
     return launch_fft_rows_exchange_chunk(in_f2, out_f2, log2n2, rows, world, tw_log2n, row0, direction, s, 1, rows, 0);
 }
 
-// DSP_GPU_REAL_HALF_14=0/1 (A/B): whether rows of 2^14 real samples take the half-length form too
+// DSP_GPU_REAL_HALF_14=0/1 (A/B): whether rows of 2^13 and 2^14 real samples take the half-length form too
 static bool real_half_14() {
     const char *e = getenv("DSP_GPU_REAL_HALF_14");
     return e ? e[0] == '1' : kRealHalf14Default;
@@ -1012,6 +1012,9 @@ int launch_fft_real_batch(const float *in, size_t n_in, size_t in_stride, float2
     if (log2n == 15)  // 2^15 real samples ride one 2^14-point complex transform: still a single HBM pass
         return shifted ? launch_big<14, true, true, true>(in, out, batch, n_in, in_stride, direction, s)
                        : launch_big<14, true, false, true>(in, out, batch, n_in, in_stride, direction, s);
+    if (log2n == 13 && real_half_14())  // 2^13 real samples ride a 4096-point transform: 382 -> 458 GSamples/s
+        return shifted ? launch_big<12, true, true, true>(in, out, batch, n_in, in_stride, direction, s)
+                       : launch_big<12, true, false, true>(in, out, batch, n_in, in_stride, direction, s);
     if (log2n == 14 && real_half_14())
         return shifted ? launch_big<13, true, true, true>(in, out, batch, n_in, in_stride, direction, s)
                        : launch_big<13, true, false, true>(in, out, batch, n_in, in_stride, direction, s);

@@ -241,7 +241,7 @@ def test_single_pass_8k_16k(ops, dev, orc, log2n, batch):
     assert torch.equal(buf, X)
 
 
-@pytest.mark.parametrize("log2n", [15, 16, 18, 21, 25])
+@pytest.mark.parametrize("log2n", [13, 14, 15, 16, 18, 21, 25])
 def test_real_half_length_route_equals_full_length(ops, dev, log2n, monkeypatch):
     """Rows of 2^15 samples and more ride a half-length complex transform (N/2 trick, spectrum unfolded in the last
     pass); the full-length route stays selectable: both must agree, with and without dsp::shift."""
@@ -255,7 +255,7 @@ def test_real_half_length_route_equals_full_length(ops, dev, log2n, monkeypatch)
         monkeypatch.setenv("DSP_GPU_REAL_HALF_LARGE", half)
         monkeypatch.setenv("DSP_GPU_REAL_HALF_14", half)
         got[half] = (ops.fft(x, n), ops.fft(x, n, inverse=True, shift=True))
-    if log2n >= 16:
+    if log2n != 15:  # (2^15 has no full-length single-pass form to compare with)
         for a, b in zip(got["1"], got["0"]):
             den = torch.linalg.vector_norm(b.view(torch.float32).double())
             assert float(torch.linalg.vector_norm((a - b).view(torch.float32).double()) / den) <= budget(log2n)
