@@ -31,6 +31,7 @@ EXPORTS = (
     "dsp_gpu_moving_average",
     "dsp_gpu_iir",
     "dsp_gpu_iir_multi",
+    "dsp_gpu_iir_settle",
     "dsp_gpu_device_count",
     "dsp_gpu_last_error_string",
     "dsp_gpu_shutdown",
@@ -73,6 +74,8 @@ def lib() -> C.CDLL:
         vp, sz, i = C.c_void_p, C.c_size_t, C.c_int
         L.dsp_gpu_fft_batch.argtypes = [vp, vp, i, sz, i, i, vp]
         L.dsp_gpu_fft_batch_f64.argtypes = [vp, vp, i, sz, i, i, vp]
+        L.dsp_gpu_iir_settle.argtypes = [vp, vp, i, C.POINTER(sz)]
+        L.dsp_gpu_iir_settle.restype = i
         L.dsp_gpu_fft_batch_f64.restype = i
         L.dsp_gpu_fft_batch_noalloc.argtypes = [vp, vp, i, sz, i, vp]
         L.dsp_gpu_fft_batch_noalloc.restype = i

@@ -569,6 +569,21 @@ int dsp_gpu_iir(const float *x, float *y, size_t channels, size_t n, const doubl
         state, state_bytes);
 }
 
+int dsp_gpu_iir_settle(const double *a, const double *b, int poles, size_t *samples) {
+    if (!a || !b || !samples) return fail(DSP_GPU_EINVAL, "dsp_gpu_iir_settle: null argument");
+    if (poles < 1 || poles > 20) return fail(DSP_GPU_EINVAL, "dsp_gpu_iir_settle: poles %d outside [1,20]", poles);
+    IirCoef co{};
+    co.poles = poles;
+    for (int i = 0; i <= poles; ++i) {
+        co.a[i] = a[i];
+        co.b[i] = i == 0 ? 0.0 : b[i];
+        if (!std::isfinite(co.a[i]) || !std::isfinite(co.b[i])) return fail(DSP_GPU_EINVAL, "dsp_gpu_iir_settle: non-finite coefficient");
+    }
+    co.c0 = 1.0;
+    co.d0 = 0.0;
+    return iir_settle_samples(co, samples);
+}
+
 int dsp_gpu_iir_multi(const float *x, float *y, size_t channels, size_t n, const double *a, const double *b, int poles,
                       const double *c0, const double *d0, double *state, int mem, void *stream) {
     if (!x || !y || !a || !b) return fail(DSP_GPU_EINVAL, "dsp_gpu_iir_multi: null buffer");

@@ -142,6 +142,7 @@ struct IirPerChannel {
 // per_channel == nullptr: `co` for every channel; otherwise only co.poles is read from `co` (poles <= 8).
 int launch_iir_batch(const float *x, float *y, size_t channels, size_t n, const IirCoef &co, double *state,
                      const IirPerChannel *per_channel, hipStream_t s);
+int iir_settle_samples(const IirCoef &co, size_t *samples);
 int launch_iir_scan(const float *x, float *y, size_t channels, size_t n, const IirCoef &co, double *state,
                     hipStream_t s);
 

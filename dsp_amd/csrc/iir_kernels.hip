@@ -1064,6 +1064,22 @@ bool is_aligned(const float *x, const float *y, size_t n) {
 
 }  // namespace
 
+// Samples after which the response to ANY initial state has decayed below 2^-44 of it (||A^k||_inf <= 2^-44 for the
+// companion matrix A of the feedback part): what a time-sharded run needs to know -- a segment started `samples` early,
+// or re-run over its first `samples` outputs from the true state, is exact to double rounding from there on.
+int iir_settle_samples(const IirCoef &co, size_t *samples) {
+    const std::shared_ptr<const ScanPlan> plan = cached_plan(co);
+    if (plan->warm >= 0) {
+        *samples = static_cast<size_t>(plan->warm);
+        return DSP_GPU_OK;
+    }
+    if (plan->decay > 0) {  // (A^4096)^j <= 2^-60: a coarser but safe bound
+        *samples = static_cast<size_t>(plan->decay) * kTile;
+        return DSP_GPU_OK;
+    }
+    return fail(DSP_GPU_EUNSUPPORTED, "dsp_gpu_iir_settle: the filter's state does not decay within %d samples", 64 * kTile);
+}
+
 bool iir_tables_in_use(int dev) { return tables_in_use(dev); }
 void release_iir_tables(int dev) { release_tables(dev); }
 

@@ -223,6 +223,19 @@ def iir(x, a, b, c0: float = 1.0, d0: float = 0.0, state=None, mode: str = "auto
     return y
 
 
+def iir_settle(a, b) -> int:
+    """Samples after which the response to any initial state has decayed below 2^-44 of it (dsp_gpu_iir_settle);
+    host arithmetic only."""
+    import ctypes as C
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    if a.size != b.size:
+        raise capi.DspGpuError(capi.EINVAL, "a and b must have poles+1 entries each")
+    out = C.c_size_t(0)
+    capi.check(capi.lib().dsp_gpu_iir_settle(a.ctypes.data, b.ctypes.data, a.size - 1, C.byref(out)))
+    return int(out.value)
+
+
 def iir_multi(x, a, b, c0=None, d0=None, state=None, out=None):
     """Filter bank: channel k runs its own Coefficients (a[k], b[k], c0[k], d0[k]); a, b [channels, poles+1]
     float64, c0/d0 [channels] float64 or None (1 and 0), all living where x lives.  Block-wise form of a

@@ -176,6 +176,17 @@ int dsp_gpu_iir(const float *x, float *y, size_t channels, size_t n, const doubl
                 void *stream);
 
 /*
+ * How long a filter remembers: the number of samples (a multiple of 64) after which the response to ANY initial state
+ * {x[t-1..], v[t-1..]} has decayed below 2^-44 of it -- ||A^k||_inf <= 2^-44 for the companion matrix of the feedback
+ * coefficients b (coefficients.h:116-118).  Host arithmetic only (no GPU work).  It is what splitting ONE long
+ * channel over several GPUs in time needs (dsp_amd/multigpu.py iir_time_sharded): every GPU filters
+ * its segment from a zero state, the end states are gathered, and each GPU re-runs only its first `samples` outputs
+ * from its predecessor's end state -- exact to double rounding when a segment is at least `samples` long.
+ * DSP_GPU_EUNSUPPORTED for filters that do not decay within 262,144 samples (marginally stable ones).
+ */
+int dsp_gpu_iir_settle(const double *a, const double *b, int poles, size_t *samples);
+
+/*
  * The same recursion with ONE COEFFICIENT SET PER CHANNEL (a filter bank: every channel its own
  * Coefficients<poles> object, e.g. a bank of band-pass filters tuned differently, the block-wise form of
  * eval/signals/wind_generator.h:150-167, which retunes its band-pass as it runs).  a, b: [channels][poles+1]
