@@ -59,6 +59,7 @@ def parse():
 # ----------------------------------------------------------------------------------------------
 SECONDARY = ("fir_direct", "fir_os", "iir_batch", "iir_scan", "mavg")  # timed after the headline FFT in the default run
 SHARD = (0, 1)  # (rank, world) when --scaling strong channel-shards the one-GPU batch
+TIME_SHARD = False  # --scaling strong under torch.distributed (also at world 1 with DSP_BENCH_INIT_DIST): C4b cut in time
 
 
 def _share(total):
@@ -158,11 +159,20 @@ def make_iir(torch, dev, ops, rank, mode):
         channels, n = 1, 1 << 28
         wl = "C4b: 4-pole Chebyshev low-pass, one 2^28-sample channel (block-parallel scan), per GPU"
     g = torch.Generator(device=dev).manual_seed(777 + rank)
+    time_sharded = mode == "scan" and TIME_SHARD
+    if time_sharded:  # --scaling strong: the ONE channel is cut in time, one segment per GPU (multigpu.iir_time_sharded)
+        from dsp_amd import multigpu
+        lo, hi = multigpu.shard_range(n, *SHARD)
+        n = hi - lo
+        wl = f"C4b: 4-pole Chebyshev low-pass, one 2^28-sample channel cut in time over {SHARD[1]} GPU(s), {n} samples on this one"
     x = torch.randn(channels, n, device=dev, generator=g)
     y = torch.empty_like(x)
 
     def step():
-        ops.iir(x, a, b, mode=mode, out=y)
+        if time_sharded:
+            multigpu.iir_time_sharded(x, a, b, rank=SHARD[0], world=SHARD[1], mode=mode)
+        else:
+            ops.iir(x, a, b, mode=mode, out=y)
 
     meta = dict(metric=f"iir_{mode}_throughput", unit="GSamples/s", dtype="f32", bound="hbm", alg_per_unit=8.0,
                 alg_unit="bytes/sample (4 B read + 4 B write)", kernel=f"iir_{mode}_kernel",
@@ -305,8 +315,10 @@ def main():
     from dsp_amd import multigpu, ops
 
     global SHARD
+    global TIME_SHARD
     if args.scaling == "strong":
         SHARD = (rank, world)
+        TIME_SHARD = use_dist
 
     def barrier():
         if use_dist:
