@@ -107,3 +107,14 @@ def test_limits(ops, dev):
     L = capi.lib()
     assert L.dsp_gpu_fft_batch_f64(x.data_ptr(), x.data_ptr(), 25, 1, capi.FORWARD, capi.MEM_DEVICE, None) == capi.EINVAL
     assert L.dsp_gpu_fft_batch_f64(None, x.data_ptr(), 3, 1, capi.FORWARD, capi.MEM_DEVICE, None) == capi.EINVAL
+
+
+@pytest.mark.parametrize("log2n,batch", [(10, 3000), (18, 5), (22, 1)])
+def test_host_pointers_equal_device_pointers(ops, dev, log2n, batch):
+    """numpy in / numpy out (the host route: chunked through the page-locked ring, or whole when one transform is larger
+    than a ring slot) gives the device route's bits."""
+    import torch
+    rng = np.random.default_rng(64 + log2n)
+    x = rng.standard_normal((batch, 1 << log2n)) + 1j * rng.standard_normal((batch, 1 << log2n))
+    want = ops.fft0_f64(torch.from_numpy(x).to(dev)).cpu().numpy()
+    assert np.array_equal(ops.fft0_f64(x), want)
