@@ -310,7 +310,10 @@ __global__ __launch_bounds__(kPlaneThreads) void fft_plane_kernel(const void *__
             const bool pairs = (in_stride & 1) == 0 && (reinterpret_cast<uintptr_t>(in_) & 7) == 0;
             if (pairs && n_in >= static_cast<size_t>(2 * N)) {  // no padding, 8-byte aligned rows: the row IS the complex input
 #pragma unroll
-                for (int m = 0; m < P; ++m) r[m] = load_stream(reinterpret_cast<const c32 *>(src) + lt + T * m);
+                for (int i = 0; i < P; ++i) {  // even points first: the first radix-32 butterfly takes r[0], r[2], ... and
+                    const int m = 2 * (i % (P / 2)) + i / (P / 2);  // starts while the odd ones are still on their way (+3 %)
+                    r[m] = load_stream(reinterpret_cast<const c32 *>(src) + lt + T * m);
+                }
             } else {
                 // zero padding (fft.h:65-74) by the hardware: buffer loads of a descriptor that ends with the row return 0
                 // beyond it -- no branch around any load, no lane masks, all loads in flight together
@@ -328,7 +331,10 @@ __global__ __launch_bounds__(kPlaneThreads) void fft_plane_kernel(const void *__
         } else {
             const c32 *src = static_cast<const c32 *>(in_) + t * N;
 #pragma unroll
-            for (int m = 0; m < P; ++m) r[m] = load_stream(src + lt + T * m);
+            for (int i = 0; i < P; ++i) {  // even points first (see above)
+                const int m = 2 * (i % (P / 2)) + i / (P / 2);
+                r[m] = load_stream(src + lt + T * m);
+            }
         }
         stockham_pass<32, 1, LOG2N, SIGN, P>(r, lt);
         plane_exchange<1>(r, plane_lds, lt);
