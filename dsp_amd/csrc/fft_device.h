@@ -296,8 +296,18 @@ DSP_DEV c32 unit_root_wide(unsigned long long num, int log2den) {
 //   index inside its transform.  r[m] holds element lt + T*m of the pass input.
 //   The thread owns B = P/R butterflies j = lt + T*s; butterfly s reads r[s + t*B] and
 //   leaves output u in r[s + u*B].  NS = product of the radices of the earlier passes.
+template <int R, int NS, int LOG2N, int SIGN, int P, typename After>
+DSP_DEV void stockham_pass(c32 (&r)[P], int lt, After after);
+
 template <int R, int NS, int LOG2N, int SIGN, int P>
 DSP_DEV void stockham_pass(c32 (&r)[P], int lt) {
+    stockham_pass<R, NS, LOG2N, SIGN, P>(r, lt, [](int) {});
+}
+
+// `after(s)` runs once butterfly s has left its outputs in r[s + u*B]: a last pass can send them on their way while the
+// next butterfly is computed
+template <int R, int NS, int LOG2N, int SIGN, int P, typename After>
+DSP_DEV void stockham_pass(c32 (&r)[P], int lt, After after) {
     constexpr int N = 1 << LOG2N;
     constexpr int T = N / P;
     constexpr int B = P / R;
@@ -327,6 +337,7 @@ DSP_DEV void stockham_pass(c32 (&r)[P], int lt) {
         Dft<R, SIGN>::run(v);
 #pragma unroll
         for (int u = 0; u < R; ++u) r[s + u * B] = v[u];
+        after(s);
     }
 }
 

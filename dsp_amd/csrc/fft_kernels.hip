@@ -340,7 +340,20 @@ __global__ __launch_bounds__(kPlaneThreads) void fft_plane_kernel(const void *__
         plane_exchange<1>(r, plane_lds, lt);
         stockham_pass<32, 32, LOG2N, SIGN, P>(r, lt);
         plane_exchange<32>(r, plane_lds, lt);
-        stockham_pass<32, 1024, LOG2N, SIGN, P>(r, lt);
+        if constexpr (REAL_HALF) {
+            stockham_pass<32, 1024, LOG2N, SIGN, P>(r, lt);
+        } else {
+            // the outputs of each of the last pass's two butterflies leave as soon as they exist
+            stockham_pass<32, 1024, LOG2N, SIGN, P>(r, lt, [&](int sb) {
+#pragma unroll
+                for (int u = 0; u < 32; ++u) {
+                    int k = lt + T * (sb + 2 * u);
+                    if constexpr (SHIFTED) k = (k + N / 2) & (N - 1);
+                    store_stream(out + t * N + k, r[sb + 2 * u]);
+                }
+            });
+            continue;
+        }
         if constexpr (REAL_HALF) {
             // Z[k], k = lt + T m, in natural order through the image once more, a plane at a time: bin k needs Z[N - k].
             // With zc = conj Z[N - k]:  E = (Z + zc)/2, i O = (Z - zc)/2, X[k] = E + W_2N^k O, X[k + N] = E - W_2N^k O.
