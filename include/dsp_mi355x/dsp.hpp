@@ -37,6 +37,7 @@
 #include <iterator>
 #include <stdexcept>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../dsp_gpu.h"
@@ -110,9 +111,28 @@ void fft0_device(const void *in, void *out, int log2n, size_t batch, void *strea
 // fft.h:57-83: real samples -> complex spectrum of 2^ceil(log2 nf) points, zero padded.
 template <FFTType type = FFTType::FORWARD, typename TimeDomainIterator, typename ComplexIterator>
 void fft(TimeDomainIterator tdFirst, TimeDomainIterator tdLast, ComplexIterator c_out, int nf) {
+    assert(nf >= 2);
+    using In = typename std::iterator_traits<TimeDomainIterator>::value_type;
+    if constexpr (std::is_same_v<In, double>) {
+        // double samples: the reference's own arithmetic (it widens everything to complex<double>, fft.h:60-74)
+        const int lg = static_cast<int>(std::ceil(std::log2(nf)));
+        if (lg <= 24) {
+            std::vector<std::complex<double>> buf(static_cast<size_t>(1) << lg);  // zero padded
+            size_t i = 0;
+            for (auto it = tdFirst; it != tdLast && i < buf.size(); ++it, ++i) buf[i] = std::complex<double>(*it, 0.0);
+            check(dsp_gpu_fft_batch_f64(buf.data(), buf.data(), lg, 1, type == FFTType::FORWARD ? DSP_GPU_FORWARD : DSP_GPU_INVERSE,
+                                        DSP_GPU_MEM_HOST, nullptr),
+                  "fft");
+            using Out = typename std::iterator_traits<ComplexIterator>::value_type;
+            for (const auto &c : buf) {
+                *c_out = Out(c.real(), c.imag());
+                ++c_out;
+            }
+            return;
+        }
+    }
     std::vector<float> td;
     for (auto it = tdFirst; it != tdLast; ++it) td.push_back(static_cast<float>(*it));
-    assert(nf >= 2);
     const int log2n = static_cast<int>(std::ceil(std::log2(nf)));
     std::vector<std::complex<float>> out(static_cast<size_t>(1) << log2n);
     if (td.empty()) td.push_back(0.0f);

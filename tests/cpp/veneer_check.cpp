@@ -90,6 +90,15 @@ int run(const std::string &dir) {
         fft0<FFTType::FORWARD>(in.data(), fwd.data(), 10, in.size() / 1024);
         dump(dir + "/fft_fwd.c128", fwd.data(), fwd.size());
     }
+    // dsp::fft on DOUBLE samples (fft.h:57-83 widens to complex<double>): 1000 samples zero padded to 1024, double route
+    {
+        auto in32 = slurp<std::complex<float>>(dir + "/fft_in.c64");
+        std::vector<double> td(1000);
+        for (size_t i = 0; i < td.size(); ++i) td[i] = in32[i].real();
+        std::vector<std::complex<double>> freq(1024);
+        fft(td.begin(), td.end(), freq.begin(), 1024);
+        dump(dir + "/fft_real_double.c128", freq.data(), freq.size());
+    }
     // eval/recursive_filters/main.cpp:104-121: impulse at N/2 -> filter -> 1024-point fft
     {
         SampleBuffer<float> impulse(1024, 0.0f);

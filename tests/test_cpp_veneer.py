@@ -67,6 +67,7 @@ def test_veneer_on_gpu(tmp_path, orc, golden, dev):
     assert rel_l2(rd("fft_fwd.c64", np.complex64).reshape(3, 1024), fwd) <= 1e-4
     assert rel_l2(rd("fft_back.c64", np.complex64).reshape(3, 1024), 1024 * fft_in.astype(np.complex128)) <= 2e-4
     assert rel_l2(rd("fft_fwd.c128", np.complex128).reshape(3, 1024), fwd) <= 1e-13  # double route: the reference's own type
+    assert rel_l2(rd("fft_real_double.c128", np.complex128), orc.fft_real(fft_in[0].real[:1000].astype(np.float64), 1024)) <= 1e-13
 
     assert rel_l2(rd("chain_response.f32", np.float32), orc.iir(np.eye(1, 1024, 512)[0], golden["cheby_lp4_a"], golden["cheby_lp4_b"])) <= 2e-6
     resp = rd("chain_response.f32", np.float32).astype(np.float64)
