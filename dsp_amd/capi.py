@@ -32,6 +32,7 @@ EXPORTS = (
     "dsp_gpu_iir",
     "dsp_gpu_iir_multi",
     "dsp_gpu_iir_settle",
+    "dsp_gpu_biquad_swept",
     "dsp_gpu_device_count",
     "dsp_gpu_last_error_string",
     "dsp_gpu_shutdown",
@@ -88,6 +89,8 @@ def lib() -> C.CDLL:
         L.dsp_gpu_iir.argtypes = [vp, vp, sz, sz, vp, vp, i, C.c_double, C.c_double, vp, i, i, vp]
         L.dsp_gpu_iir_multi.argtypes = [vp, vp, sz, sz, vp, vp, i, vp, vp, vp, i, vp]
         L.dsp_gpu_iir_multi.restype = i
+        L.dsp_gpu_biquad_swept.argtypes = [vp, vp, vp, sz, sz, sz, i, C.c_double, vp, i, vp]
+        L.dsp_gpu_biquad_swept.restype = i
         L.dsp_gpu_fft_columns.argtypes = [vp, vp, i, sz, i, vp]
         L.dsp_gpu_swap_axes.argtypes = [vp, vp, sz, sz, sz, i, sz, i, vp]
         L.dsp_gpu_transpose_blocks.argtypes = [vp, vp, sz, sz, sz, vp]

@@ -636,6 +636,45 @@ int dsp_gpu_iir_multi(const float *x, float *y, size_t channels, size_t n, const
     return DSP_GPU_OK;
 }
 
+int dsp_gpu_biquad_swept(const float *x, const float *fc, float *y, size_t channels, size_t n, size_t fc_stride, int kind,
+                         double bandwidth, double *state, int mem, void *stream) {
+    if (!x || !fc || !y) return fail(DSP_GPU_EINVAL, "dsp_gpu_biquad_swept: null buffer");
+    if (kind != DSP_GPU_SWEPT_BANDPASS && kind != DSP_GPU_SWEPT_BANDREJECT)
+        return fail(DSP_GPU_EINVAL, "dsp_gpu_biquad_swept: kind %d", kind);
+    if (!std::isfinite(bandwidth)) return fail(DSP_GPU_EINVAL, "dsp_gpu_biquad_swept: non-finite bandwidth");
+    if (bad_mem(mem)) return fail(DSP_GPU_EINVAL, "dsp_gpu_biquad_swept: mem %d", mem);
+    if (channels == 0 || n == 0) return DSP_GPU_OK;
+    if (fc_stride != 0 && fc_stride != n)
+        return fail(DSP_GPU_EINVAL, "dsp_gpu_biquad_swept: fc_stride %zu is neither 0 (one sweep for all channels) nor n", fc_stride);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t bytes = channels * n * sizeof(float);
+    const size_t fc_bytes = (fc_stride ? channels : 1) * n * sizeof(float);
+    const size_t state_bytes = channels * 4 * sizeof(double);
+    // every tile is read (x and fc) before it is written, so y == x is in place; so is y == fc when each channel has
+    // its own sweep.  Anything else that overlaps is refused.
+    if (device_overlap(x, y, bytes, mem) && x != y) return fail(DSP_GPU_EINVAL, "dsp_gpu_biquad_swept: x and y overlap");
+    if (device_overlap(fc, y, std::max(bytes, fc_bytes), mem) && (fc != y || fc_stride == 0))
+        return fail(DSP_GPU_EINVAL, "dsp_gpu_biquad_swept: fc and y overlap");
+    if (mem == DSP_GPU_MEM_DEVICE) return launch_biquad_swept(x, fc, y, channels, n, fc_stride, kind, bandwidth, state, s);
+    HostStage hs;
+    if (int rc = stage_in(x, bytes, bytes, s, &hs)) return rc;
+    void *p = nullptr;
+    if (int rc = workspace(WS_SCRATCH_A, fc_bytes, &p)) return rc;
+    float *dfc = static_cast<float *>(p);
+    DSPGPU_HIP(hipMemcpyAsync(dfc, fc, fc_bytes, hipMemcpyHostToDevice, s));
+    double *dstate = nullptr;
+    if (state) {
+        if (int rc = workspace(WS_STATE, state_bytes, &p)) return rc;
+        dstate = static_cast<double *>(p);
+        DSPGPU_HIP(hipMemcpyAsync(dstate, state, state_bytes, hipMemcpyHostToDevice, s));
+    }
+    if (int rc = launch_biquad_swept(static_cast<const float *>(hs.d_in), dfc, static_cast<float *>(hs.d_out), channels, n,
+                                     fc_stride, kind, bandwidth, dstate, s))
+        return rc;
+    if (state) DSPGPU_HIP(hipMemcpyAsync(state, dstate, state_bytes, hipMemcpyDeviceToHost, s));
+    return stage_out(y, bytes, s, hs);
+}
+
 int dsp_gpu_fft_columns(const void *in, void *out, int log2n, size_t cols, int direction, void *stream) {
     if (!in || !out) return fail(DSP_GPU_EINVAL, "dsp_gpu_fft_columns: null buffer");
     if (direction != DSP_GPU_FORWARD && direction != DSP_GPU_INVERSE)

@@ -145,5 +145,9 @@ int launch_iir_batch(const float *x, float *y, size_t channels, size_t n, const 
 int iir_settle_samples(const IirCoef &co, size_t *samples);
 int launch_iir_scan(const float *x, float *y, size_t channels, size_t n, const IirCoef &co, double *state,
                     hipStream_t s);
+// A band-pass (kind 0) / band-reject (kind 1) BiQuad redesigned at every sample from fc[ch * fc_stride + t]
+// (iir_swept_kernels.hip); state [channels][4] = {x1, x2, y1, y2}, may be null.
+int launch_biquad_swept(const float *x, const float *fc, float *y, size_t channels, size_t n, size_t fc_stride, int kind,
+                        double bandwidth, double *state, hipStream_t s);
 
 }  // namespace dspgpu

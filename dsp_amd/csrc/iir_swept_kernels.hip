@@ -1,0 +1,217 @@
+// iir_swept_kernels.hip -- a band-pass / band-reject BiQuad retuned at EVERY sample, for gfx950 (MI355X).
+//
+// Stands in for the loop of eval/signals/wind_generator.h:150-167 (Whistling::getSample): per sample
+//     bp = dsp::recursive::bandPassFilter(fc[t], bw)        recursive_filters.h:165-186 (bandReject :188-209)
+//     m_bp.a = bp.a; m_bp.b = bp.b;                          the history x1,x2,y1,y2 stays
+//     y[t] = m_bp(x[t])                                      coefficients.h:172-182, all in double
+// i.e. a two-pole recursion whose five coefficients are designed anew from the centre frequency of that sample.
+// The design is elementwise (one cos and one division in double per sample), the recursion is sequential, so the
+// unit of parallelism is the channel, as in iir_batch_kernel: a wave owns 64 channels and walks time in tiles staged
+// through two padded LDS tiles (samples and centre frequencies), the next tile's loads in flight while this one is
+// computed.  Arithmetic follows the reference operation by operation in double WITHOUT contraction (this file is
+// built with -ffp-contract=off, see the Makefile): what differs from a CPU run is the last bit of cos().
+//
+// Bound: fp64 VALU, not HBM: ~110 double-precision instructions per sample (cos ~70, the division ~12, the design
+// and the recursion ~25) against 12 B/sample of traffic (x and fc in, y out).
+#include <cmath>
+
+#include "common.h"
+
+namespace dspgpu {
+namespace {
+
+#define DSP_DEV __device__ __forceinline__
+
+constexpr int kWave = 64;
+constexpr double kRefPi = 3.1415926535897932384626433832795;  // constants.h:4
+
+struct SweptState {
+    double x1, x2, y1, y2;
+};
+
+// One sample: design (recursive_filters.h:165-209) then the BiQuad step (coefficients.h:172-182), in the reference's
+// own order of operations.  r = 1 - 3*BW and rr = r*r are the same for every sample and come from the host.
+template <int KIND>
+DSP_DEV float swept_step(float sample, float cf, double r, double rr, SweptState &st) {
+    const double c = cos(2 * kRefPi * static_cast<double>(cf));
+    const double k = (1 - 2 * r * c + rr) / (2 - 2 * c);
+    double a0, a1, a2;
+    if (KIND == 0) {
+        a0 = 1 - k;
+        a1 = 2 * (k - r) * c;
+        a2 = rr - k;
+    } else {
+        a0 = k;
+        a1 = -2 * k * c;
+        a2 = k;
+    }
+    const double b1 = 2 * r * c;
+    const double b2 = -rr;
+    const double s = static_cast<double>(sample);
+    double y = a0 * s + a1 * st.x1 + a2 * st.x2;
+    y += b1 * st.y1 + b2 * st.y2;
+    st.x2 = st.x1;
+    st.x1 = s;
+    st.y2 = st.y1;
+    st.y1 = y;
+    return static_cast<float>(y);  // c0 = 1, d0 = 0: what both designers leave (coefficients.h:70-71)
+}
+
+// T samples per tile row.  64 rows (one per lane = channel) of T + 4 floats: rows stay 16-byte aligned and lanes walking
+// their own rows with 16-byte LDS accesses are conflict-free (lane stride = 4 mod 64 dwords for T = 64 and 128).
+template <int T>
+struct SweptShape {
+    static constexpr int kPad = T + 4;
+    static constexpr int kLanesPerRow = T / 4;               // lanes covering one row with float4
+    static constexpr int kRowsPerIter = kWave / kLanesPerRow;  // rows per wave instruction
+    static constexpr int kIters = kWave / kRowsPerIter;        // float4 loads per lane per tile and array
+};
+
+template <int T, bool ALIGNED>
+DSP_DEV void swept_load(const float *__restrict__ p0, size_t stride, size_t channels, size_t n, size_t ch0, size_t t0,
+                        int lane, float4 (&pre)[SweptShape<T>::kIters]) {
+    using S = SweptShape<T>;
+#pragma unroll
+    for (int it = 0; it < S::kIters; ++it) {
+        const size_t ch = ch0 + it * S::kRowsPerIter + lane / S::kLanesPerRow;
+        const size_t g = t0 + (lane % S::kLanesPerRow) * 4;
+        float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (ch < channels) {
+            const float *p = p0 + ch * stride + g;
+            if (ALIGNED && g + 3 < n) {
+                v = load_stream_f4(p);
+            } else {
+                if (g < n) v.x = p[0];
+                if (g + 1 < n) v.y = p[1];
+                if (g + 2 < n) v.z = p[2];
+                if (g + 3 < n) v.w = p[3];
+            }
+        }
+        pre[it] = v;
+    }
+}
+
+template <int T>
+DSP_DEV void swept_stage(float *tile, int lane, const float4 (&pre)[SweptShape<T>::kIters]) {
+    using S = SweptShape<T>;
+#pragma unroll
+    for (int it = 0; it < S::kIters; ++it)
+        *reinterpret_cast<float4 *>(tile + (it * S::kRowsPerIter + lane / S::kLanesPerRow) * S::kPad +
+                                    (lane % S::kLanesPerRow) * 4) = pre[it];
+}
+
+// fc_stride: n (every channel its own sweep) or 0 (one sweep shared by all channels).
+// state: [channels][4] doubles {x1, x2, y1, y2} (the BiQuad's members, coefficients.h:52-68), in/out, may be null.
+template <int KIND, int T, bool ALIGNED>
+__global__ __launch_bounds__(kWave) void biquad_swept_kernel(const float *__restrict__ x, const float *__restrict__ fc,
+                                                              float *__restrict__ y, size_t channels, size_t n,
+                                                              size_t fc_stride, double r, double rr,
+                                                              double *__restrict__ state, size_t groups, size_t chunk) {
+    using S = SweptShape<T>;
+    __shared__ __attribute__((aligned(16))) float xt[kWave * S::kPad];
+    __shared__ __attribute__((aligned(16))) float ft[kWave * S::kPad];
+    const int lane = threadIdx.x;
+    const size_t group = xcd_tile_of(blockIdx.x, chunk);  // each XCD owns a contiguous range of channels
+    if (group >= groups) return;
+    const size_t ch0 = group * kWave;
+    const size_t ch = ch0 + lane;
+    const bool live = ch < channels;
+
+    SweptState st{0.0, 0.0, 0.0, 0.0};
+    if (live && state) {
+        st.x1 = state[ch * 4 + 0];
+        st.x2 = state[ch * 4 + 1];
+        st.y1 = state[ch * 4 + 2];
+        st.y2 = state[ch * 4 + 3];
+    }
+
+    const size_t ntiles = (n + T - 1) / T;
+    float4 px[S::kIters], pf[S::kIters];
+    swept_load<T, ALIGNED>(x, n, channels, n, ch0, 0, lane, px);
+    swept_load<T, ALIGNED>(fc, fc_stride, channels, n, ch0, 0, lane, pf);
+    for (size_t tl = 0; tl < ntiles; ++tl) {
+        const size_t t0 = tl * T;
+        swept_stage<T>(xt, lane, px);
+        swept_stage<T>(ft, lane, pf);
+        __syncthreads();
+        if (tl + 1 < ntiles) {
+            swept_load<T, ALIGNED>(x, n, channels, n, ch0, t0 + T, lane, px);
+            swept_load<T, ALIGNED>(fc, fc_stride, channels, n, ch0, t0 + T, lane, pf);
+        }
+        if (live) {
+            float *xr = xt + lane * S::kPad;
+            const float *fr = ft + lane * S::kPad;
+            const int count = t0 + T <= n ? T : static_cast<int>(n - t0);
+            if (count == T) {
+#pragma unroll 2
+                for (int i = 0; i < T; i += 4) {
+                    float4 q = *reinterpret_cast<const float4 *>(xr + i);
+                    const float4 f = *reinterpret_cast<const float4 *>(fr + i);
+                    q.x = swept_step<KIND>(q.x, f.x, r, rr, st);
+                    q.y = swept_step<KIND>(q.y, f.y, r, rr, st);
+                    q.z = swept_step<KIND>(q.z, f.z, r, rr, st);
+                    q.w = swept_step<KIND>(q.w, f.w, r, rr, st);
+                    *reinterpret_cast<float4 *>(xr + i) = q;
+                }
+            } else {
+#pragma unroll 1
+                for (int i = 0; i < count; ++i) xr[i] = swept_step<KIND>(xr[i], fr[i], r, rr, st);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < S::kIters; ++it) {
+            const size_t c = ch0 + it * S::kRowsPerIter + lane / S::kLanesPerRow;
+            const size_t g = t0 + (lane % S::kLanesPerRow) * 4;
+            if (c >= channels || g >= n) continue;
+            const float *src = xt + (it * S::kRowsPerIter + lane / S::kLanesPerRow) * S::kPad + (lane % S::kLanesPerRow) * 4;
+            float *p = y + c * n + g;
+            if (ALIGNED && g + 3 < n) {
+                const float4 q = *reinterpret_cast<const float4 *>(src);
+                store_stream_f4(p, q.x, q.y, q.z, q.w);
+            } else {
+                p[0] = src[0];
+                if (g + 1 < n) p[1] = src[1];
+                if (g + 2 < n) p[2] = src[2];
+                if (g + 3 < n) p[3] = src[3];
+            }
+        }
+        __syncthreads();
+    }
+    if (live && state) {
+        state[ch * 4 + 0] = st.x1;
+        state[ch * 4 + 1] = st.x2;
+        state[ch * 4 + 2] = st.y1;
+        state[ch * 4 + 3] = st.y2;
+    }
+}
+
+template <int KIND, bool ALIGNED>
+int swept_dispatch(const float *x, const float *fc, float *y, size_t channels, size_t n, size_t fc_stride, double bw,
+                   double *state, hipStream_t s) {
+    constexpr int T = 64;  // 2 x 17 KB of LDS: four one-wave workgroups per CU, one per SIMD
+    const size_t groups = (channels + kWave - 1) / kWave;
+    const size_t chunk = (groups + 7) / 8;
+    if (8 * chunk > 0x7fffffffull) return fail(DSP_GPU_EUNSUPPORTED, "swept biquad: too many channels");
+    const double r = 1 - 3 * bw;  // recursive_filters.h:168
+    hipLaunchKernelGGL((biquad_swept_kernel<KIND, T, ALIGNED>), dim3(static_cast<unsigned>(8 * chunk)), dim3(kWave), 0, s,
+                       x, fc, y, channels, n, fc_stride, r, r * r, state, groups, chunk);
+    return check_launch("biquad_swept_kernel");
+}
+
+}  // namespace
+
+int launch_biquad_swept(const float *x, const float *fc, float *y, size_t channels, size_t n, size_t fc_stride, int kind,
+                        double bandwidth, double *state, hipStream_t s) {
+    const bool al = n % 4 == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0 && reinterpret_cast<uintptr_t>(y) % 16 == 0 &&
+                    reinterpret_cast<uintptr_t>(fc) % 16 == 0;
+    if (kind == 0)
+        return al ? swept_dispatch<0, true>(x, fc, y, channels, n, fc_stride, bandwidth, state, s)
+                  : swept_dispatch<0, false>(x, fc, y, channels, n, fc_stride, bandwidth, state, s);
+    if (kind == 1)
+        return al ? swept_dispatch<1, true>(x, fc, y, channels, n, fc_stride, bandwidth, state, s)
+                  : swept_dispatch<1, false>(x, fc, y, channels, n, fc_stride, bandwidth, state, s);
+    return fail(DSP_GPU_EINVAL, "swept biquad: kind %d", kind);
+}
+
+}  // namespace dspgpu

@@ -266,6 +266,45 @@ def iir_multi(x, a, b, c0=None, d0=None, state=None, out=None):
     return y
 
 
+_SWEPT_KINDS = {"bandpass": 0, "bandreject": 1}
+
+
+def biquad_swept(x, fc, bandwidth: float, kind: str = "bandpass", state=None, out=None):
+    """A band-pass / band-reject BiQuad retuned at every sample (dsp_gpu_biquad_swept): per sample the design of
+    recursive_filters.h:165-209 at centre frequency fc[t], then one BiQuad step (coefficients.h:172-182) -- the
+    loop of eval/signals/wind_generator.h:150-167.  x float32 [..., n]; fc float32 of the same shape (a sweep per
+    channel) or [n] (one sweep for all channels), living where x lives; state float64 [channels, 4] = {x1, x2, y1,
+    y2}, carried across calls."""
+    x, px, mem = _prep(x, np.float32, "float32")
+    n = x.shape[-1]
+    channels = int(np.prod(x.shape[:-1])) if x.ndim > 1 else 1
+    if _is_torch(fc) != _is_torch(x):
+        raise capi.DspGpuError(capi.EINVAL, "fc must live where x lives")
+    fc, pfc, _ = _prep(fc, np.float32, "float32")
+    if tuple(fc.shape) == tuple(x.shape):
+        stride = n
+    elif tuple(fc.shape) == (n,):
+        stride = 0
+    else:
+        raise capi.DspGpuError(capi.EINVAL, "fc must have x's shape or be one sweep of n samples")
+    if kind not in _SWEPT_KINDS:
+        raise capi.DspGpuError(capi.EINVAL, f"kind {kind!r}")
+    pstate = None
+    if state is not None:
+        if _is_torch(state) != _is_torch(x):
+            raise capi.DspGpuError(capi.EINVAL, "state must live where x lives")
+        ok = (state.is_contiguous() and state.dtype == torch.float64 and state.numel() == channels * 4) \
+            if _is_torch(state) else (state.flags.c_contiguous and state.dtype == np.float64 and state.size == channels * 4)
+        if not ok:
+            raise capi.DspGpuError(capi.EINVAL, "state must be contiguous float64 [channels, 4]")
+        pstate = _ptr(state)
+    y = _out(out, x, tuple(x.shape), np.float32, "float32")
+    with _on_device(x):
+        capi.check(capi.lib().dsp_gpu_biquad_swept(px, pfc, _ptr(y), channels, n, stride, _SWEPT_KINDS[kind],
+                                                   float(bandwidth), pstate, mem, _stream_of(x)))
+    return y
+
+
 def fft_kernel_ms(x, out, inverse: bool, iters: int) -> float:
     """Average milliseconds per batched-FFT launch, timed with HIP events on x's stream."""
     n = x.shape[-1]

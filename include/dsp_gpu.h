@@ -198,6 +198,30 @@ int dsp_gpu_iir_multi(const float *x, float *y, size_t channels, size_t n, const
                       int poles, const double *c0, const double *d0, double *state, int mem, void *stream);
 
 /*
+ * A band-pass / band-reject BiQuad RETUNED AT EVERY SAMPLE.  Replaces the loop of eval/signals/wind_generator.h:150-167
+ * (Whistling::getSample), which per sample designs dsp::recursive::bandPassFilter(fc, bw) (recursive_filters.h:165-186;
+ * kind DSP_GPU_SWEPT_BANDREJECT: bandRejectFilter, :188-209), copies its a and b into a BiQuad that keeps its history,
+ * and steps that BiQuad once (coefficients.h:172-182):
+ *     R = 1 - 3*bw;  c = cos(2*PI*fc[t]);  K = (1 - 2Rc + R^2) / (2 - 2c)
+ *     band-pass  a = {1-K, 2(K-R)c, R^2-K}     band-reject  a = {K, -2Kc, K}      b = {0, 2Rc, -R^2}
+ *     v = a0 x[t] + a1 x1 + a2 x2;  v += b1 y1 + b2 y2;  (x2,x1,y2,y1) <- (x1,x[t],y1,v);  y[t] = v
+ * Design and recursion run on the device in double, operation for operation as in the reference and without fused
+ * multiply-adds; only cos() may differ from a CPU's in its last bit.  x, y: [channels][n] fp32.  fc: centre frequency
+ * per sample as a fraction of the sample rate, in (0, 0.5], fp32 (the reference computes it in float,
+ * wind_generator.h:157-158): [channels][n] with fc_stride == n, or ONE sweep [n] shared by all channels with
+ * fc_stride == 0.  fc[t] == 0 divides by zero exactly as the reference does (K = NaN).  bandwidth: as the reference's
+ * second argument (fraction of the sample rate).  `state`: [channels][4] doubles {x1, x2, y1, y2} -- the BiQuad's
+ * members (coefficients.h:52-68) -- read before, written after, may be NULL (= from rest); it lets a long run be fed in
+ * blocks (blocked == unblocked bit for bit).  y == x (and y == fc when fc_stride == n) is in place.  One lane per
+ * channel: tens of thousands of channels fill the chip.  Bound by double-precision arithmetic (~110 instructions per
+ * sample), not by its 12 B/sample of traffic.
+ */
+#define DSP_GPU_SWEPT_BANDPASS 0
+#define DSP_GPU_SWEPT_BANDREJECT 1
+int dsp_gpu_biquad_swept(const float *x, const float *fc, float *y, size_t channels, size_t n, size_t fc_stride,
+                         int kind, double bandwidth, double *state, int mem, void *stream);
+
+/*
  * Local steps of the multi-GPU six-step FFT: one dsp::fft0 (fft.h:31-55) of N = N1*N2 points spread
  * over G GPUs, n = n1*N2 + n2, k = k1 + N1*k2 (BASELINE config 5) -- the building blocks that
  * dsp_gpu_fft_dist (below) sequences around its three all-to-all exchanges.  DEVICE pointers

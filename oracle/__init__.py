@@ -199,6 +199,24 @@ class OracleLib:
             fn(p(xi[r]), C.c_size_t(xi.shape[1]), _d(a), _d(b), C.c_double(c0), C.c_double(d0), sp, p(yi[r]))
         return y
 
+    def biquad_swept(self, x, fc, bw: float, kind="bandpass", state=None):
+        """eval/signals/wind_generator.h:150-167: the BiQuad redesigned from fc[t] before every step.
+        x float32 [n] or [ch, n]; fc float32 of x's shape or [n]; state [ch, 4] doubles, updated in place."""
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        fc = np.ascontiguousarray(fc, dtype=np.float32)
+        y = np.empty_like(x)
+        xi, yi = x.reshape(-1, x.shape[-1]), y.reshape(-1, x.shape[-1])
+        fi = np.broadcast_to(fc, x.shape).reshape(xi.shape)
+        if state is not None:
+            assert state.dtype == np.float64 and state.size == xi.shape[0] * 4
+            st = state.reshape(xi.shape[0], 4)
+        fn = self._fn("biquad_swept_f32")
+        for r in range(xi.shape[0]):
+            sp = _d(st[r]) if state is not None else None
+            fn(_f(xi[r]), _f(np.ascontiguousarray(fi[r])), C.c_size_t(xi.shape[1]), C.c_int(BIQUAD_KIND[kind]),
+               C.c_double(bw), sp, _f(yi[r]))
+        return y
+
 
 _cache: dict[str, OracleLib] = {}
 

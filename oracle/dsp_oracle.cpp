@@ -411,4 +411,19 @@ void ORC_NAME(biquad_f64)(const double *x, size_t n, const double *a, const doub
     biquad_run<double>(x, n, a, b, c0, d0, state, y);
 }
 
+// ref: eval/signals/wind_generator.h:150-167 (Whistling::getSample).  Per sample: design
+// bandPassFilter(fc[t], bw) (kind 0; kind 1: bandRejectFilter) as above, overwrite the BiQuad's a and b,
+// keep its history, run one step (coefficients.h:172-182).  fc is float there (:157-158) and widens
+// exactly; c0 = 1, d0 = 0 are the BiQuad's defaults (coefficients.h:70-71).  state: {x1,x2,y1,y2}.
+void ORC_NAME(biquad_swept_f32)(const float *x, const float *fc, size_t n, int kind, double bw, double *state,
+                                float *y) {
+    double local[4] = {0, 0, 0, 0};
+    double *st = state ? state : local;
+    double a[3], b[3], cd[2];
+    for (size_t i = 0; i < n; ++i) {
+        ORC_NAME(biquad_design)(kind, static_cast<double>(fc[i]), bw, 0.0, a, b, cd);
+        biquad_run<float>(x + i, 1, a, b, 1.0, 0.0, st, y + i);
+    }
+}
+
 }  // extern "C"

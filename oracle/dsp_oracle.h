@@ -73,6 +73,10 @@ void ORC_NAME(biquad_f32)(const float *x, size_t n, const double *a, const doubl
                           double c0, double d0, double *state, float *y);
 void ORC_NAME(biquad_f64)(const double *x, size_t n, const double *a, const double *b,
                           double c0, double d0, double *state, double *y);
+/* eval/signals/wind_generator.h:150-167: the band-pass (kind 0) / band-reject (kind 1) BiQuad redesigned from
+ * fc[t] before every step; state {x1,x2,y1,y2} in/out, may be NULL */
+void ORC_NAME(biquad_swept_f32)(const float *x, const float *fc, size_t n, int kind, double bw,
+                                double *state, float *y);
 
 #ifdef __cplusplus
 }

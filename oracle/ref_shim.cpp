@@ -241,4 +241,28 @@ void ref_biquad_f64(const double *x, size_t n, const double *a, const double *b,
     run_biquad<double>(x, n, a, b, c0, d0, state, y);
 }
 
+// The retuned band-pass of eval/signals/wind_generator.h:156-164, with the reference's own designer and BiQuad:
+// design, overwrite a and b, step.  (The wind-speed synthesis around it needs choc, which is absent; fc comes in.)
+void ref_biquad_swept_f32(const float *x, const float *fc, size_t n, int kind, double bw, double *state, float *y) {
+    dsp::BiQuad m_bp{};
+    if (state) {
+        m_bp.x1 = state[0];
+        m_bp.x2 = state[1];
+        m_bp.y1 = state[2];
+        m_bp.y2 = state[3];
+    }
+    for (size_t i = 0; i < n; ++i) {
+        auto bp = kind == 0 ? dsp::recursive::bandPassFilter(fc[i], bw) : dsp::recursive::bandRejectFilter(fc[i], bw);
+        m_bp.a = bp.a;
+        m_bp.b = bp.b;
+        y[i] = m_bp(x[i]);
+    }
+    if (state) {
+        state[0] = m_bp.x1;
+        state[1] = m_bp.x2;
+        state[2] = m_bp.y1;
+        state[3] = m_bp.y2;
+    }
+}
+
 }  // extern "C"

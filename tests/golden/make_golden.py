@@ -18,6 +18,7 @@ follow what the reference's eval programs look at (file:line relative to /root/r
   cheby_*      recursive_filters.h:153-163 designs + 4096-sample noise responses
   bq_*         recursive_filters.h:165-263 designs + responses (shelves exercise c0/d0)
   chain_*      eval/recursive_filters/main.cpp:104-121  impulse@N/2 -> filter -> 1024-pt fft
+  swept_*      eval/signals/wind_generator.h:150-167    band-pass redesigned from fc[t] before every step
 """
 import os
 import sys
@@ -145,6 +146,24 @@ def main():
     resp = ref.biquad(imp1k, a, b, c0, d0)
     g["chain_pk_response"] = resp
     g["chain_pk_fft"] = ref.fft_real(resp, 1024)
+
+    # --- the band-pass retuned every sample: eval/signals/wind_generator.h:150-167 -------------------
+    # Whistling wh0{400, 600, ...} and wh1{1000, 1000, ...} of eval/signals/main.cpp:33-34 at 44.1 kHz.  The wind
+    # speed they follow comes out of choc's oscillator (absent here), so a 20 Hz raised sine stands in for it; the
+    # centre frequency is computed in float as wind_generator.h:157-158 does, the bandwidth is its 60.f/sampleRate.
+    # (No new random draws: everything above keeps its values.)
+    sr44 = np.float32(44100)
+    tt = np.arange(4096, dtype=np.float32)
+    ws = (np.float32(0.5) + np.float32(0.5) * np.sin(np.float32(2 * np.pi * 20) * tt / sr44)).astype(np.float32)
+    bw = float(np.float32(60) / sr44)
+    g["swept_bw"] = np.array([bw])
+    for tag, lower, upper in (("wh0", 400, 600), ("wh1", 1000, 1000)):
+        fc = ((ws * np.float32(lower) + np.float32(upper)) / sr44).astype(np.float32)
+        g[f"swept_{tag}_fc"] = fc
+        st = np.zeros(4)
+        g[f"swept_{tag}_y32"] = ref.biquad_swept(x4k, fc, bw, "bandpass", state=st)
+        g[f"swept_{tag}_state"] = st.copy()
+    g["swept_wh0_reject_y32"] = ref.biquad_swept(x4k, g["swept_wh0_fc"], bw, "bandreject")
 
     out = os.path.join(ROOT, "tests", "golden", "dsp_golden.npz")
     np.savez_compressed(out, **g)

@@ -51,6 +51,11 @@ def test_argument_errors_without_a_gpu():
     assert L.dsp_gpu_iir(p, p, 1, 8, p, p, 21, 1.0, 0.0, None, 0, 1, None) == capi.EINVAL
     assert L.dsp_gpu_iir_multi(p, p, 1, 8, p, p, 9, None, None, None, 1, None) == capi.EINVAL
     assert L.dsp_gpu_iir_multi(p, p, 0, 8, p, p, 2, None, None, None, 1, None) == capi.OK
+    assert L.dsp_gpu_biquad_swept(p, None, p, 1, 8, 8, 0, 0.01, None, 1, None) == capi.EINVAL   # no sweep
+    assert L.dsp_gpu_biquad_swept(p, p, p, 1, 8, 8, 2, 0.01, None, 1, None) == capi.EINVAL      # kind
+    assert L.dsp_gpu_biquad_swept(p, p, p, 1, 8, 4, 0, 0.01, None, 1, None) == capi.EINVAL      # fc_stride not 0 / n
+    assert L.dsp_gpu_biquad_swept(p, p, p, 1, 8, 8, 0, 0.01, None, 7, None) == capi.EINVAL      # mem
+    assert L.dsp_gpu_biquad_swept(p, p, p, 0, 8, 8, 0, 0.01, None, 1, None) == capi.OK
     with pytest.raises(capi.DspGpuError):
         capi.check(capi.EINVAL)
 

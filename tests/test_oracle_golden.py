@@ -145,3 +145,25 @@ def test_chain_impulse_filter_fft(orc, golden):
     resp = orc.biquad(imp, a, b, c0, d0)
     assert same(resp, golden["chain_pk_response"])
     assert same(orc.fft_real(resp, 1024), golden["chain_pk_fft"])
+
+
+@pytest.mark.parametrize("tag", ["wh0", "wh1"])
+def test_swept_bandpass(orc, golden, tag):
+    # eval/signals/wind_generator.h:150-167: design from fc[t], overwrite a and b, one BiQuad step -- per sample
+    x, fc, bw = golden["iir_noise_in"], golden[f"swept_{tag}_fc"], float(golden["swept_bw"][0])
+    st = np.zeros(4)
+    assert same(orc.biquad_swept(x, fc, bw, "bandpass", state=st), golden[f"swept_{tag}_y32"])
+    assert same(st, golden[f"swept_{tag}_state"])
+    # fed in blocks with the BiQuad's members carried: nothing changes
+    st = np.zeros(4)
+    y = np.concatenate([orc.biquad_swept(x[:999], fc[:999], bw, state=st), orc.biquad_swept(x[999:], fc[999:], bw, state=st)])
+    assert same(y, golden[f"swept_{tag}_y32"]) and same(st, golden[f"swept_{tag}_state"])
+    # a constant sweep is the fixed band-pass
+    fconst = np.full(x.size, fc[0], dtype=np.float32)
+    a, b, c0, d0 = orc.biquad_design("bandpass", float(fc[0]), bw)
+    assert same(orc.biquad_swept(x, fconst, bw), orc.biquad(x, a, b, c0, d0))
+
+
+def test_swept_bandreject(orc, golden):
+    x, fc, bw = golden["iir_noise_in"], golden["swept_wh0_fc"], float(golden["swept_bw"][0])
+    assert same(orc.biquad_swept(x, fc, bw, "bandreject"), golden["swept_wh0_reject_y32"])

@@ -94,3 +94,20 @@ def test_biquad(orc, ref, kind, args):
         y0 = np.concatenate([orc.biquad(xx[:777], *d0, state=s0), orc.biquad(xx[777:], *d0, state=s0)])
         y1 = np.concatenate([ref.biquad(xx[:777], *d1, state=s1), ref.biquad(xx[777:], *d1, state=s1)])
         assert same(y0, y1) and same(s0, s1)
+
+
+@pytest.mark.parametrize("kind", ["bandpass", "bandreject"])
+def test_biquad_swept(orc, ref, kind):
+    # the retuned band-pass of eval/signals/wind_generator.h:150-167, against the reference's own designer + BiQuad
+    rng = np.random.default_rng(21)
+    x = rng.standard_normal((3, 2500)).astype(np.float32)
+    t = np.arange(2500)
+    fc = (0.02 + rng.uniform(0.0, 0.4, size=(3, 1)) * (0.5 + 0.5 * np.sin(rng.uniform(0.001, 0.05, size=(3, 1)) * t))).astype(np.float32)
+    s0, s1 = rng.standard_normal((3, 4)), None
+    s1 = s0.copy()
+    y0 = np.concatenate([orc.biquad_swept(x[:, :701], fc[:, :701], 0.004, kind, state=s0),
+                         orc.biquad_swept(x[:, 701:], fc[:, 701:], 0.004, kind, state=s0)], axis=1)
+    y1 = np.concatenate([ref.biquad_swept(x[:, :701], fc[:, :701], 0.004, kind, state=s1),
+                         ref.biquad_swept(x[:, 701:], fc[:, 701:], 0.004, kind, state=s1)], axis=1)
+    assert same(y0, y1) and same(s0, s1)
+    assert same(orc.biquad_swept(x, fc[0], 0.004, kind), ref.biquad_swept(x, fc[0], 0.004, kind))  # one sweep for all
