@@ -9,13 +9,17 @@
 // unit of parallelism is the channel, as in iir_batch_kernel: a wave owns 64 channels and walks time in tiles staged
 // through two padded LDS tiles (samples and centre frequencies), the next tile's loads in flight while this one is
 // computed.  Arithmetic follows the reference operation by operation in double WITHOUT contraction (this file is
-// built with -ffp-contract=off, see the Makefile): what differs from a CPU run is the last bit of cos().
+// built with -ffp-contract=off, see the Makefile): what differs from a CPU run is the last bit of cos() (swept_cos.h:
+// within one ulp of the host library's, checked on the host by tests/cpp/swept_cos_check.cpp).
 //
-// Bound: fp64 VALU, not HBM: ~110 double-precision instructions per sample (cos ~70, the division ~12, the design
-// and the recursion ~25) against 12 B/sample of traffic (x and fc in, y out).
+// Bound: double-precision VALU first, HBM second: ~70 double-precision instructions per sample (cos ~30, the IEEE
+// division ~12, the design and the recursion ~25) against 12 B/sample of traffic (x and fc in, y out).  With the
+// general library cos (~90 instructions, a double-double argument reduction this range never needs) the kernel ran
+// 4.4-4.6 ms on 262,144 x 4,096.
 #include <cmath>
 
 #include "common.h"
+#include "swept_cos.h"
 
 namespace dspgpu {
 namespace {
@@ -23,7 +27,6 @@ namespace {
 #define DSP_DEV __device__ __forceinline__
 
 constexpr int kWave = 64;
-constexpr double kRefPi = 3.1415926535897932384626433832795;  // constants.h:4
 
 struct SweptState {
     double x1, x2, y1, y2;
@@ -33,19 +36,22 @@ struct SweptState {
 // own order of operations.  r = 1 - 3*BW and rr = r*r are the same for every sample and come from the host.
 template <int KIND>
 DSP_DEV float swept_step(float sample, float cf, double r, double rr, SweptState &st) {
-    const double c = cos(2 * kRefPi * static_cast<double>(cf));
-    const double k = (1 - 2 * r * c + rr) / (2 - 2 * c);
+    const double c = swept_cos(cf);  // cos(2 * PI * cf), recursive_filters.h:169
+    // Doubling is exact, so 2*r*c == r*(2c), 2*(k-r)*c == (k-r)*(2c) and -2*k*c == -(k*(2c)) bit for bit: 2c is formed
+    // once.  Everything else is the reference's expression, operation for operation.
+    const double c2 = c + c;
+    const double b1 = r * c2;                       // 2 * R * cos2pif
+    const double k = (1 - b1 + rr) / (2 - c2);      // (1 - 2*R*cos2pif + R*R) / (2 - 2*cos2pif)
     double a0, a1, a2;
     if (KIND == 0) {
         a0 = 1 - k;
-        a1 = 2 * (k - r) * c;
+        a1 = (k - r) * c2;                          // 2 * (K - R) * cos2pif
         a2 = rr - k;
     } else {
         a0 = k;
-        a1 = -2 * k * c;
+        a1 = -(k * c2);                             // -2 * K * cos2pif
         a2 = k;
     }
-    const double b1 = 2 * r * c;
     const double b2 = -rr;
     const double s = static_cast<double>(sample);
     double y = a0 * s + a1 * st.x1 + a2 * st.x2;
@@ -58,7 +64,8 @@ DSP_DEV float swept_step(float sample, float cf, double r, double rr, SweptState
 }
 
 // T samples per tile row.  64 rows (one per lane = channel) of T + 4 floats: rows stay 16-byte aligned and lanes walking
-// their own rows with 16-byte LDS accesses are conflict-free (lane stride = 4 mod 64 dwords for T = 64 and 128).
+// their own rows with 16-byte LDS accesses: lane stride T + 4 dwords (36 for T = 32: the 16 lanes of one access group
+// start in 16 different 4-bank groups).
 template <int T>
 struct SweptShape {
     static constexpr int kPad = T + 4;
@@ -189,7 +196,10 @@ __global__ __launch_bounds__(kWave) void biquad_swept_kernel(const float *__rest
 template <int KIND, bool ALIGNED>
 int swept_dispatch(const float *x, const float *fc, float *y, size_t channels, size_t n, size_t fc_stride, double bw,
                    double *state, hipStream_t s) {
-    constexpr int T = 64;  // 2 x 17 KB of LDS: four one-wave workgroups per CU, one per SIMD
+    // 32-sample rows: 2 x 9 KB of LDS per one-wave workgroup, so eight of them fit a CU = two waves per SIMD, which this
+    // arithmetic-bound kernel needs more than it needs long row segments (measured on 262,144 x 4,096, per-channel
+    // sweeps: 32-sample rows 3.33 ms, 64: 3.76 ms, 128: 7.6 ms -- two workgroups per CU and spills)
+    constexpr int T = 32;
     const size_t groups = (channels + kWave - 1) / kWave;
     const size_t chunk = (groups + 7) / 8;
     if (8 * chunk > 0x7fffffffull) return fail(DSP_GPU_EUNSUPPORTED, "swept biquad: too many channels");

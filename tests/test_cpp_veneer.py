@@ -91,3 +91,16 @@ def test_veneer_on_gpu(tmp_path, orc, golden, dev):
     assert rel_l2(rd("iir_ls.f32", np.float32), golden["bq_ls_y64"]) <= 2e-6
     rows = iir_in.reshape(4, -1).astype(np.float64)
     assert rel_l2(rd("iir_rows.f32", np.float32).reshape(4, -1), orc.iir(rows, golden["cheby_lp4_a"], golden["cheby_lp4_b"])) <= 2e-6
+
+
+def test_swept_cos_matches_libm():
+    """dsp_amd/csrc/swept_cos.h (the cosine inside the per-sample band-pass design, recursive_filters.h:169) compiled
+    for the host, against the C library's cos over 2^24 frequencies in [0, 0.5], the quadrant edges and tiny
+    frequencies: never more than one ulp (of the result, and 2^-53 absolute) away."""
+    exe = os.path.join(ROOT, "tests", "cpp", "swept_cos_check")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "cpp"), "swept_cos_check"], check=True, capture_output=True)
+    out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout.split()
+    got = dict(zip(out[0::2], out[1::2]))
+    assert float(got["max_abs_ulp1"]) <= 1.0 and float(got["max_rel_ulp"]) <= 1.0, got
+    assert int(got["samples"]) > (1 << 24) and float(got["wild_abs"]) < 1e-12, got
