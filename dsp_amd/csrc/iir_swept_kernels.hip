@@ -12,10 +12,12 @@
 // built with -ffp-contract=off, see the Makefile): what differs from a CPU run is the last bit of cos() (swept_cos.h:
 // within one ulp of the host library's, checked on the host by tests/cpp/swept_cos_check.cpp).
 //
-// Bound: double-precision VALU first, HBM second: ~70 double-precision instructions per sample (cos ~30, the IEEE
-// division ~12, the design and the recursion ~25) against 12 B/sample of traffic (x and fc in, y out).  With the
-// general library cos (~90 instructions, a double-double argument reduction this range never needs) the kernel ran
-// 4.4-4.6 ms on 262,144 x 4,096.
+// Bound: double-precision VALU first, HBM second: ~60-70 instructions per sample (cos 18-30, the IEEE division ~12, the
+// design and the recursion ~25, conversions) against 12 B/sample of traffic (x and fc in, y out); under this fp64 load
+// the chip clocks at ~1.65 GHz (SQ_BUSY_CYCLES, profiles/r02_biquad_swept_pmc.txt).  262,144 voices x 4,096 samples:
+// 4.57 ms with the library cos (~90 instructions, a double-double argument reduction this range never needs) and
+// 64-sample rows; 3.68 ms with swept_cos.h; 3.25 ms with 32-sample rows (two waves per SIMD); 3.04 ms with the four
+// cosines of a float4 evaluated together and the sine kernel skipped per wave = 353 GSamples/s, 4.2 TB/s.
 #include <cmath>
 
 #include "common.h"
@@ -32,11 +34,11 @@ struct SweptState {
     double x1, x2, y1, y2;
 };
 
-// One sample: design (recursive_filters.h:165-209) then the BiQuad step (coefficients.h:172-182), in the reference's
-// own order of operations.  r = 1 - 3*BW and rr = r*r are the same for every sample and come from the host.
+// One sample, given c = cos(2*PI*fc[t]): design (recursive_filters.h:165-209) then the BiQuad step
+// (coefficients.h:172-182), in the reference's own order of operations.  r = 1 - 3*BW and rr = r*r are the same for
+// every sample and come from the host.
 template <int KIND>
-DSP_DEV float swept_step(float sample, float cf, double r, double rr, SweptState &st) {
-    const double c = swept_cos(cf);  // cos(2 * PI * cf), recursive_filters.h:169
+DSP_DEV float swept_apply(float sample, double c, double r, double rr, SweptState &st) {
     // Doubling is exact, so 2*r*c == r*(2c), 2*(k-r)*c == (k-r)*(2c) and -2*k*c == -(k*(2c)) bit for bit: 2c is formed
     // once.  Everything else is the reference's expression, operation for operation.
     const double c2 = c + c;
@@ -61,6 +63,39 @@ DSP_DEV float swept_step(float sample, float cf, double r, double rr, SweptState
     st.y2 = st.y1;
     st.y1 = y;
     return static_cast<float>(y);  // c0 = 1, d0 = 0: what both designers leave (coefficients.h:70-71)
+}
+
+template <int KIND>
+DSP_DEV float swept_step(float sample, float cf, double r, double rr, SweptState &st) {
+    return swept_apply<KIND>(sample, swept_cos(cf), r, rr, st);  // cos(2 * PI * cf), recursive_filters.h:169
+}
+
+// Four consecutive samples of a lane.  The four cosines do not depend on the recursion, so they are evaluated together
+// (four independent polynomial chains to interleave); and the sine kernel is evaluated only when some lane of the WAVE
+// needs it for one of the four (a wave-uniform branch): voices that stay below fc = 1/8 -- anything audible at audio
+// rates -- never do.
+template <int KIND>
+DSP_DEV float4 swept_step4(float4 q, float4 f, double r, double rr, SweptState &st) {
+    const float cf[4] = {f.x, f.y, f.z, f.w};
+    double n[4], t[4], c[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) swept_cos_reduce(cf[i], n[i], t[i]);
+    const bool sine = n[0] == 1.0 || n[1] == 1.0 || n[2] == 1.0 || n[3] == 1.0;
+    if (__builtin_amdgcn_ballot_w64(sine) == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const double cs = swept_cos_kernel(t[i]);
+            c[i] = n[i] == 0.0 ? cs : -cs;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) c[i] = swept_cos_pick(n[i], swept_sin_kernel(t[i]), swept_cos_kernel(t[i]));
+    }
+    q.x = swept_apply<KIND>(q.x, c[0], r, rr, st);
+    q.y = swept_apply<KIND>(q.y, c[1], r, rr, st);
+    q.z = swept_apply<KIND>(q.z, c[2], r, rr, st);
+    q.w = swept_apply<KIND>(q.w, c[3], r, rr, st);
+    return q;
 }
 
 // T samples per tile row.  64 rows (one per lane = channel) of T + 4 floats: rows stay 16-byte aligned and lanes walking
@@ -154,10 +189,7 @@ __global__ __launch_bounds__(kWave) void biquad_swept_kernel(const float *__rest
                 for (int i = 0; i < T; i += 4) {
                     float4 q = *reinterpret_cast<const float4 *>(xr + i);
                     const float4 f = *reinterpret_cast<const float4 *>(fr + i);
-                    q.x = swept_step<KIND>(q.x, f.x, r, rr, st);
-                    q.y = swept_step<KIND>(q.y, f.y, r, rr, st);
-                    q.z = swept_step<KIND>(q.z, f.z, r, rr, st);
-                    q.w = swept_step<KIND>(q.w, f.w, r, rr, st);
+                    q = swept_step4<KIND>(q, f, r, rr, st);
                     *reinterpret_cast<float4 *>(xr + i) = q;
                 }
             } else {
@@ -198,7 +230,7 @@ int swept_dispatch(const float *x, const float *fc, float *y, size_t channels, s
                    double *state, hipStream_t s) {
     // 32-sample rows: 2 x 9 KB of LDS per one-wave workgroup, so eight of them fit a CU = two waves per SIMD, which this
     // arithmetic-bound kernel needs more than it needs long row segments (measured on 262,144 x 4,096, per-channel
-    // sweeps: 32-sample rows 3.33 ms, 64: 3.76 ms, 128: 7.6 ms -- two workgroups per CU and spills)
+    // sweeps, at the time: 32-sample rows 3.33 ms, 64: 3.76 ms, 128: 7.6 ms -- two workgroups per CU and spills)
     constexpr int T = 32;
     const size_t groups = (channels + kWave - 1) / kWave;
     const size_t chunk = (groups + 7) / 8;

@@ -28,7 +28,8 @@
  *     dsp_gpu_fft_rows_exchange, dsp_gpu_convolve_stream (history scratch), dsp_gpu_iir with `state` or in
  *     a SCAN form that carries tile states, dsp_gpu_iir_multi from host memory, and
  *     dsp_gpu_fft_batch_noalloc (its fixed array).  Calls that touch no workspace -- device-pointer FFTs up
- *     to 2^15 points, dsp_gpu_convolve, dsp_gpu_moving_average, dsp_gpu_iir BATCH without state -- may run
+ *     to 2^15 points, dsp_gpu_convolve, dsp_gpu_moving_average, dsp_gpu_iir BATCH without state,
+ *     dsp_gpu_biquad_swept -- may run
  *     concurrently on different streams.
  */
 #ifndef DSP_GPU_H

@@ -23,7 +23,9 @@ def main():
     t = torch.arange(n, device=dev, dtype=torch.float32)
     rate = torch.rand(ch, 1, generator=g, device=dev) * 0.02 + 0.001
     per_channel = (0.05 + 0.04 * torch.sin(rate * t)).contiguous()  # smooth sweeps: random jumps are not a stable filter
-    for label, fc in (("per-channel sweep", per_channel), ("one sweep for all", per_channel[0].contiguous())):
+    wide = (0.23 + 0.22 * torch.sin(rate * t)).contiguous()  # all three quadrants of the cosine inside every wave
+    for label, fc in (("per-channel sweep", per_channel), ("one sweep for all", per_channel[0].contiguous()),
+                      ("sweeps 0.01..0.45", wide)):
         for kind in ("bandpass", "bandreject"):
             for _ in range(2):
                 ops.biquad_swept(x, fc, 60.0 / 44100.0, kind=kind, out=y)
