@@ -18,6 +18,7 @@
 //   Coefficients<P>::operator()(buffer)  coefficients.h:88   Coefficients<P>::operator()(buf)
 //   Coefficients<P>::operator()(buffer, CircularBuffer&)  coefficients.h:132,197   operator()(buf, sink)
 //   recursive::lowPassFilter<P>(fc) ...  recursive_filters.h:153-263   same names
+//   the retuning loop of eval/signals/wind_generator.h:156-164         recursive::bandPassSwept(filter, in, fc, bw)
 //
 // Buffers: any type with size(), data() and a (size_t) constructor works -- the reference's own
 // dsp::SampleBuffer<float> as well as the small SampleBuffer below.  Errors: like the reference
@@ -511,6 +512,40 @@ inline BiQuad narrowBand(double f, double bw, bool reject) {  // recursive_filte
 }  // namespace detail
 inline BiQuad bandPassFilter(double centerFrequency, double bandwidth) { return detail::narrowBand(centerFrequency, bandwidth, false); }
 inline BiQuad bandRejectFilter(double centerFrequency, double bandwidth) { return detail::narrowBand(centerFrequency, bandwidth, true); }
+
+// The band-pass (or band-reject) RETUNED AT EVERY SAMPLE, as eval/signals/wind_generator.h:156-164 does it one sample at
+// a time: `bp = bandPassFilter(fc[t], bw); filter.a = bp.a; filter.b = bp.b; out[t] = filter(in[t]);` for a whole block
+// in one call, design included, on the GPU.  `filter` keeps its history across calls exactly as m_bp does there, and
+// leaves with the a and b of the last sample's design; its c0 / d0 are not applied (the designers leave them 1 and 0).
+template <typename Buffer, typename Sweep>
+Buffer bandPassSwept(BiQuad &filter, const Buffer &input, const Sweep &centerFrequency, double bandwidth, bool reject = false) {
+    assert(centerFrequency.size() == input.size());
+    Buffer output(input.size());
+    if (input.size() == 0) return output;
+    std::vector<float> fc(input.size());
+    for (size_t i = 0; i < fc.size(); ++i) fc[i] = static_cast<float>(centerFrequency[static_cast<int>(i)]);
+    std::array<double, 4> st{filter.x[1], filter.x[2], filter.y[1], filter.y[2]};
+    check(dsp_gpu_biquad_swept(::dsp_mi355x::detail::cptr(input), fc.data(), ::dsp_mi355x::detail::mptr(output), 1, input.size(),
+                               input.size(), reject ? DSP_GPU_SWEPT_BANDREJECT : DSP_GPU_SWEPT_BANDPASS, bandwidth, st.data(),
+                               DSP_GPU_MEM_HOST, nullptr),
+          "bandPassSwept");
+    filter.x[1] = st[0];
+    filter.x[2] = st[1];
+    filter.y[1] = st[2];
+    filter.y[2] = st[3];
+    const BiQuad last = detail::narrowBand(static_cast<double>(fc.back()), bandwidth, reject);
+    filter.a = last.a;
+    filter.b = last.b;
+    return output;
+}
+// `channels` voices at once: in, fc, out [channels][n] (fc_stride = n) or one sweep fc[n] for all (fc_stride = 0);
+// state [channels][4] = {x1, x2, y1, y2} per voice, may be nullptr.
+inline void bandPassSwept(const float *in, const float *fc, float *out, size_t channels, size_t n, size_t fc_stride,
+                          double bandwidth, double *state = nullptr, bool reject = false) {
+    check(dsp_gpu_biquad_swept(in, fc, out, channels, n, fc_stride, reject ? DSP_GPU_SWEPT_BANDREJECT : DSP_GPU_SWEPT_BANDPASS,
+                               bandwidth, state, DSP_GPU_MEM_HOST, nullptr),
+          "bandPassSwept");
+}
 
 inline BiQuad lowShelf(double frequency, double gain) {  // recursive_filters.h:211-227
     const double u = std::pow(10.0, gain / 20), v = 4.0 / (1 + u);

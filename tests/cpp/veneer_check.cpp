@@ -177,6 +177,24 @@ int run(const std::string &dir) {
         recursive::lowPassFilter<4>(0.1).apply(x.data(), rows.data(), 4, x.size() / 4);
         dump(dir + "/iir_rows.f32", rows.data(), rows.size());
     }
+    // the band-pass retuned every sample (eval/signals/wind_generator.h:156-164), in 256-frame blocks with the BiQuad's
+    // own history carried
+    {
+        auto x = slurp<float>(dir + "/iir_in.f32");
+        auto fc = slurp<float>(dir + "/swept_fc.f32");
+        BiQuad voice{};
+        std::vector<float> y;
+        for (size_t at = 0; at < x.size(); at += 256) {
+            const size_t len = std::min<size_t>(256, x.size() - at);
+            SampleBuffer<float> block(x.begin() + at, x.begin() + at + len), sweep(fc.begin() + at, fc.begin() + at + len);
+            auto yb = recursive::bandPassSwept(voice, block, sweep, 60.f / 44100.f);
+            y.insert(y.end(), yb.begin(), yb.end());
+        }
+        dump(dir + "/swept.f32", y.data(), y.size());
+        std::vector<double> members{voice.x[1], voice.x[2], voice.y[1], voice.y[2], voice.a[0], voice.a[1], voice.a[2],
+                                    voice.b[1], voice.b[2]};
+        dump(dir + "/swept_members.f64", members.data(), members.size());
+    }
     // DistributedFft: one rank holding the whole 2^16-point signal; a self "exchange" that copies (kind 3 = device
     // to device) stands where RCCL or the caller's all-to-all goes
     {

@@ -54,6 +54,7 @@ def test_veneer_on_gpu(tmp_path, orc, golden, dev):
     fir_in.tofile(os.path.join(d, "fir_in.f32"))
     iir_in = golden["iir_noise_in"]
     iir_in.tofile(os.path.join(d, "iir_in.f32"))
+    golden["swept_wh0_fc"].tofile(os.path.join(d, "swept_fc.f32"))
     dist_in = (rng.standard_normal(1 << 16) + 1j * rng.standard_normal(1 << 16)).astype(np.complex64)
     dist_in.tofile(os.path.join(d, "dist_in.c64"))
     p = subprocess.run([_exe(), "run", d], capture_output=True, text=True, timeout=110)
@@ -89,6 +90,13 @@ def test_veneer_on_gpu(tmp_path, orc, golden, dev):
     assert np.allclose(st[6:10], ref[6:10], rtol=1e-5, atol=1e-7)
     assert rel_l2(rd("iir_ring.f32", np.float32), golden["cheby_lp4_y64"]) <= 2e-6   # 256-frame blocks, object history
     assert rel_l2(rd("iir_ls.f32", np.float32), golden["bq_ls_y64"]) <= 2e-6
+    # the retuned band-pass against what the reference build produced for the same voice (golden), blocks of 256
+    swept, want = rd("swept.f32", np.float32), golden["swept_wh0_y32"]
+    assert np.abs(swept.astype(np.float64) - want).max() <= np.spacing(np.abs(want).max()) and rel_l2(swept, want.astype(np.float64)) <= 1e-7
+    members = rd("swept_members.f64", np.float64)
+    assert np.allclose(members[:4], golden["swept_wh0_state"], rtol=1e-9, atol=1e-12)
+    a, b, _, _ = orc.biquad_design("bandpass", float(golden["swept_wh0_fc"][-1]), float(golden["swept_bw"][0]))
+    assert np.array_equal(members[4:7], a) and np.array_equal(members[7:9], b[1:])  # leaves with the last design
     rows = iir_in.reshape(4, -1).astype(np.float64)
     assert rel_l2(rd("iir_rows.f32", np.float32).reshape(4, -1), orc.iir(rows, golden["cheby_lp4_a"], golden["cheby_lp4_b"])) <= 2e-6
 
