@@ -653,8 +653,11 @@ int dsp_gpu_biquad_swept(const float *x, const float *fc, float *y, size_t chann
     // every tile is read (x and fc) before it is written, so y == x is in place; so is y == fc when each channel has
     // its own sweep.  Anything else that overlaps is refused.
     if (device_overlap(x, y, bytes, mem) && x != y) return fail(DSP_GPU_EINVAL, "dsp_gpu_biquad_swept: x and y overlap");
-    if (device_overlap(fc, y, std::max(bytes, fc_bytes), mem) && (fc != y || fc_stride == 0))
-        return fail(DSP_GPU_EINVAL, "dsp_gpu_biquad_swept: fc and y overlap");
+    if (mem == DSP_GPU_MEM_DEVICE) {  // [fc, fc + fc_bytes) against [y, y + bytes): the two ranges differ in length
+        const char *f0 = reinterpret_cast<const char *>(fc), *y0 = reinterpret_cast<const char *>(y);
+        if (f0 < y0 + bytes && y0 < f0 + fc_bytes && (f0 != y0 || fc_stride == 0))
+            return fail(DSP_GPU_EINVAL, "dsp_gpu_biquad_swept: fc and y overlap");
+    }
     if (mem == DSP_GPU_MEM_DEVICE) return launch_biquad_swept(x, fc, y, channels, n, fc_stride, kind, bandwidth, state, s);
     HostStage hs;
     if (int rc = stage_in(x, bytes, bytes, s, &hs)) return rc;

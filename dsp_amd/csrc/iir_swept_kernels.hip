@@ -17,7 +17,8 @@
 // the chip clocks at ~1.65 GHz (SQ_BUSY_CYCLES, profiles/r02_biquad_swept_pmc.txt).  262,144 voices x 4,096 samples:
 // 4.57 ms with the library cos (~90 instructions, a double-double argument reduction this range never needs) and
 // 64-sample rows; 3.68 ms with swept_cos.h; 3.25 ms with 32-sample rows (two waves per SIMD); 3.04 ms with the four
-// cosines of a float4 evaluated together and the sine kernel skipped per wave = 353 GSamples/s, 4.2 TB/s.
+// cosines of a float4 evaluated together and the sine kernel skipped per wave; 2.93 ms = 367 GSamples/s, 4.4 TB/s with
+// a bounds-test-free path for full tiles.
 #include <cmath>
 
 #include "common.h"
@@ -113,6 +114,13 @@ template <int T, bool ALIGNED>
 DSP_DEV void swept_load(const float *__restrict__ p0, size_t stride, size_t channels, size_t n, size_t ch0, size_t t0,
                         int lane, float4 (&pre)[SweptShape<T>::kIters]) {
     using S = SweptShape<T>;
+    if (ALIGNED && ch0 + kWave <= channels && t0 + T <= n) {  // a full tile: no bounds tests between the loads
+        const float *p = p0 + (ch0 + lane / S::kLanesPerRow) * stride + t0 + (lane % S::kLanesPerRow) * 4;
+        const size_t step = S::kRowsPerIter * stride;
+#pragma unroll
+        for (int it = 0; it < S::kIters; ++it) pre[it] = load_stream_f4(p + it * step);
+        return;
+    }
 #pragma unroll
     for (int it = 0; it < S::kIters; ++it) {
         const size_t ch = ch0 + it * S::kRowsPerIter + lane / S::kLanesPerRow;
@@ -198,6 +206,18 @@ __global__ __launch_bounds__(kWave) void biquad_swept_kernel(const float *__rest
             }
         }
         __syncthreads();
+        if (ALIGNED && ch0 + kWave <= channels && t0 + T <= n) {  // a full tile: LDS reads and stores without bounds tests
+            const float *src = xt + (lane / S::kLanesPerRow) * S::kPad + (lane % S::kLanesPerRow) * 4;
+            float *p = y + (ch0 + lane / S::kLanesPerRow) * n + t0 + (lane % S::kLanesPerRow) * 4;
+            const size_t step = S::kRowsPerIter * n;
+#pragma unroll
+            for (int it = 0; it < S::kIters; ++it) {
+                const float4 q = *reinterpret_cast<const float4 *>(src + it * S::kRowsPerIter * S::kPad);
+                store_stream_f4(p + it * step, q.x, q.y, q.z, q.w);
+            }
+            __syncthreads();
+            continue;
+        }
 #pragma unroll
         for (int it = 0; it < S::kIters; ++it) {
             const size_t c = ch0 + it * S::kRowsPerIter + lane / S::kLanesPerRow;

@@ -151,6 +151,11 @@ def test_in_place_and_aliasing(ops, dev):
     # shifted overlap of x and y; y over a shared sweep
     assert L.dsp_gpu_biquad_swept(vp(p), vp(fc.data_ptr()), vp(p + 64), 64, 256, 256, 0, BW, None, 1, None) == capi.EINVAL
     assert L.dsp_gpu_biquad_swept(vp(p), vp(fc.data_ptr()), vp(fc.data_ptr()), 64, 512, 0, 0, BW, None, 1, None) == capi.EINVAL
+    # a shared sweep that merely sits next to y (inside y's length of it, not inside y) is fine
+    buf = torch.zeros(64 * 512 + 512, device=dev)
+    buf[:512] = fc[0]
+    ynear = buf[512:].view(64, 512)
+    assert torch.equal(ops.biquad_swept(x, buf[:512], BW, out=ynear), ops.biquad_swept(x, fc[0].contiguous(), BW))
 
 
 def test_full_size_properties(ops, dev, orc):
