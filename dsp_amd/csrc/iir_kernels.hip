@@ -126,6 +126,13 @@ DSP_DEV void batch_load(const float *__restrict__ x, size_t channels, size_t n, 
                         float4 (&pre)[kBtIters]) {
     constexpr int kLanesPerRow = kBt / 4;            // 16 lanes cover one row
     constexpr int kRowsPerIter = kWave / kLanesPerRow;  // 4 rows per wave instruction
+    if (ALIGNED && ch0 + kWave <= channels && t0 + kBt <= n) {  // a full tile: no bounds tests between the loads
+        const float *p = x + (ch0 + lane / kLanesPerRow) * n + t0 + (lane % kLanesPerRow) * 4;
+        const size_t step = kRowsPerIter * n;
+#pragma unroll
+        for (int it = 0; it < kBtIters; ++it) pre[it] = load_stream_f4(p + it * step);
+        return;
+    }
 #pragma unroll
     for (int it = 0; it < kBtIters; ++it) {
         const size_t ch = ch0 + it * kRowsPerIter + lane / kLanesPerRow;
