@@ -6,6 +6,8 @@
 //   N <= 4096   fft64_tile_kernel: 256 threads x 16 register-resident points = one 4096-point tile (4096/N transforms),
 //               radix-16 Stockham passes, points exchanged through a padded LDS image of 68 KB (two workgroups per CU).
 //               32 B of HBM traffic per point: bound by HBM like its fp32 sibling (fp64 FMA rate is not the limit).
+//   N <= 2^18   N = N1*N2, both <= 512: two passes of the same kernel, the transposes folded into its loads and stores
+//               (a tile of 4096/N1 adjacent columns, then a tile of 4096/N2 adjacent rows written transposed): 64 B/point.
 //   N <= 2^24   N = N1*N2, both <= 4096, Bailey's form with explicit transposes:
 //               [N1][N2] -T-> [N2][N1] -rows N1, x W_N^{n2 k1}-> -T-> [N1][N2] -rows N2-> -T-> X[k1 + N1 k2]
 //               five passes of 32 B per point (the twiddle rides the first row pass's stores).  Plain and correct rather
@@ -171,19 +173,51 @@ D64_DEV void exchange64(c64 (&r)[kP64], c64 *lds, int lt, int base) {
 }
 
 // 16 <= N <= 4096.  tw_log2 > 0: element k of transform q is also multiplied by exp(SIGN 2 pi i k (q % tw_rows) / 2^tw_log2),
-// the inter-step twiddle of the large route.
-template <int LOG2N, int SIGN>
-__global__ __launch_bounds__(kT64) void fft64_tile_kernel(const c64 *in, c64 *out, size_t batch,
-                                                          int tw_log2, unsigned tw_rows) {
+// the inter-step twiddle of the large routes.
+// MODE F64_ROWS    transform q is the contiguous row q of `in` / `out` (`batch` rows in all)
+//      F64_COLS    `batch` matrices [N][other]: the tile's transforms are 4096/N adjacent COLUMNS, read and written in
+//                  place of one another through the LDS image so that HBM sees runs of 4096/N elements; the twiddle row
+//                  is the column index (pass 1 of the two-pass route: over n1, times W^{n2 k1})
+//      F64_ROWS_T  `batch` matrices [other][N]: the tile's transforms are 4096/N adjacent ROWS, element k of row r goes to
+//                  out[k][r] (pass 2: over n2, X[k1 + N1 k2] lands at [k2][k1]); in != out
+enum F64Mode { F64_ROWS = 0, F64_COLS = 1, F64_ROWS_T = 2 };
+
+template <int LOG2N, int SIGN, int MODE>
+__global__ __launch_bounds__(kT64) void fft64_tile_kernel(const c64 *in, c64 *out, size_t batch, int tw_log2, unsigned tw_rows,
+                                                          unsigned other) {
     constexpr int N = 1 << LOG2N, T = N / kP64, PER_TILE = kTile64 / N;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     c64 *lds = reinterpret_cast<c64 *>(lds_raw);
     const int tid = threadIdx.x, xf = tid / T, lt = tid % T, base = xf * N;
-    const size_t q = static_cast<size_t>(blockIdx.x) * PER_TILE + xf;  // transform index
-    const bool live = q < batch;
+    size_t q;          // F64_ROWS: transform index; otherwise the twiddle row (column index) / unused
+    bool live = true;
+    const c64 *mat_in = in;
+    c64 *mat_out = out;
+    unsigned first = 0;  // first column (F64_COLS) / first row (F64_ROWS_T) of the tile inside its matrix
+    if constexpr (MODE == F64_ROWS) {
+        q = static_cast<size_t>(blockIdx.x) * PER_TILE + xf;
+        live = q < batch;
+    } else {
+        const unsigned tiles = other / PER_TILE;  // the launcher guarantees other % PER_TILE == 0
+        const size_t m = blockIdx.x / tiles;
+        first = (blockIdx.x % tiles) * PER_TILE;
+        mat_in = in + m * static_cast<size_t>(N) * other;
+        mat_out = out + m * static_cast<size_t>(N) * other;
+        q = first + xf;
+    }
     c64 r[kP64];
-    if (live) {
-        const c64 *src = in + q * N + lt;
+    if constexpr (MODE == F64_COLS) {
+#pragma unroll
+        for (int i = 0; i < kP64; ++i) {  // element e of column first + c sits at [e][first + c]: threads run along c
+            const int idx = tid + kT64 * i, c = idx % PER_TILE, e = idx / PER_TILE;
+            lds[padded64(c * N + e)] = mat_in[static_cast<size_t>(e) * other + first + c];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < kP64; ++m) r[m] = lds[padded64(base + lt + T * m)];
+        __syncthreads();
+    } else if (live) {
+        const c64 *src = (MODE == F64_ROWS ? in + q * N : mat_in + static_cast<size_t>(first + xf) * N) + lt;
 #pragma unroll
         for (int m = 0; m < kP64; ++m) r[m] = src[T * m];
     } else {
@@ -201,7 +235,7 @@ __global__ __launch_bounds__(kT64) void fft64_tile_kernel(const c64 *in, c64 *ou
             pass64<R2, R0 * R1, LOG2N, SIGN>(r, lt);
         }
     }
-    if (!live) return;
+    if (MODE == F64_ROWS && !live) return;
     if (tw_log2 > 0) {
         // W^{row k}, k = lt + T m:  W^{row lt} (W^{row T})^m -- two sincos and a product tree
         const unsigned long long mask = (1ull << tw_log2) - 1ull, row = q % tw_rows;
@@ -214,9 +248,23 @@ __global__ __launch_bounds__(kT64) void fft64_tile_kernel(const c64 *in, c64 *ou
 #pragma unroll
         for (int m = 1; m < kP64; ++m) r[m] = cmul64(r[m], cmul64(w0, pw[m]));
     }
-    c64 *dst = out + q * N + lt;
+    if constexpr (MODE == F64_ROWS) {
+        c64 *dst = out + q * N + lt;
 #pragma unroll
-    for (int m = 0; m < kP64; ++m) dst[T * m] = r[m];
+        for (int m = 0; m < kP64; ++m) dst[T * m] = r[m];
+    } else {
+        // through the image once more so that threads run along the tile's columns (F64_COLS) / rows (F64_ROWS_T), which
+        // are adjacent in the output: element e of transform c goes to out[e][first + c], rows `other` long
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < kP64; ++m) lds[padded64(base + lt + T * m)] = r[m];
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < kP64; ++i) {
+            const int idx = tid + kT64 * i, c = idx % PER_TILE, e = idx / PER_TILE;
+            mat_out[static_cast<size_t>(e) * other + first + c] = lds[padded64(c * N + e)];
+        }
+    }
 }
 
 // N = 2, 4, 8: one thread per transform
@@ -257,16 +305,23 @@ __global__ __launch_bounds__(kT64) void transpose64_kernel(const c64 *__restrict
     }
 }
 
-template <int LOG2N>
-int launch_tile(const c64 *in, c64 *out, size_t batch, int direction, int tw_log2, unsigned tw_rows, hipStream_t s) {
+template <int LOG2N, int MODE>
+int launch_tile(const c64 *in, c64 *out, size_t batch, int direction, int tw_log2, unsigned tw_rows, unsigned other,
+                hipStream_t s) {
     constexpr size_t per_tile = kTile64 >> LOG2N;
-    const size_t blocks = (batch + per_tile - 1) / per_tile;
+    size_t blocks;
+    if (MODE == F64_ROWS) {
+        blocks = (batch + per_tile - 1) / per_tile;
+    } else {
+        if (other % per_tile != 0) return fail(DSP_GPU_EINVAL, "fft64_tile_kernel: %u is not a multiple of the tile's %zu", other, per_tile);
+        blocks = batch * (other / per_tile);
+    }
     if (blocks > 0x7fffffffull) return fail(DSP_GPU_EUNSUPPORTED, "fft_batch_f64: batch too large for one launch");
-    auto kf = fft64_tile_kernel<LOG2N, +1>;
-    auto ki = fft64_tile_kernel<LOG2N, -1>;
+    auto kf = fft64_tile_kernel<LOG2N, +1, MODE>;
+    auto ki = fft64_tile_kernel<LOG2N, -1, MODE>;
     auto kern = direction == DSP_GPU_FORWARD ? kf : ki;
     if (int rc = allow_full_lds(reinterpret_cast<const void *>(kern))) return rc;
-    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks)), dim3(kT64), kLds64Bytes, s, in, out, batch, tw_log2, tw_rows);
+    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks)), dim3(kT64), kLds64Bytes, s, in, out, batch, tw_log2, tw_rows, other);
     return check_launch("fft64_tile_kernel");
 }
 
@@ -287,8 +342,30 @@ int rows64(const c64 *in, c64 *out, int log2n, size_t batch, int direction, int 
     case 2: return launch_tiny<2>(in, out, batch, direction, s);
     case 3: return launch_tiny<3>(in, out, batch, direction, s);
 #define D64_CASE(K) \
-    case K: return launch_tile<K>(in, out, batch, direction, tw_log2, tw_rows, s);
+    case K: return launch_tile<K, F64_ROWS>(in, out, batch, direction, tw_log2, tw_rows, 0, s);
         D64_CASE(4) D64_CASE(5) D64_CASE(6) D64_CASE(7) D64_CASE(8) D64_CASE(9) D64_CASE(10) D64_CASE(11) D64_CASE(12)
+#undef D64_CASE
+    }
+    return fail(DSP_GPU_EINVAL, "fft_batch_f64: row length 2^%d", log2n);
+}
+
+// The two passes of the two-pass route (N1, N2 in 2^4 .. 2^9 so that a tile spans at least 8 adjacent columns / rows):
+// `mats` matrices [2^log2n][other], transforms along the columns, in place of one another, times W_N^{col k} ...
+int cols64(const c64 *in, c64 *out, int log2n, size_t mats, unsigned other, int direction, int tw_log2, hipStream_t s) {
+    switch (log2n) {
+#define D64_CASE(K) \
+    case K: return launch_tile<K, F64_COLS>(in, out, mats, direction, tw_log2, other, other, s);
+        D64_CASE(4) D64_CASE(5) D64_CASE(6) D64_CASE(7) D64_CASE(8) D64_CASE(9)
+#undef D64_CASE
+    }
+    return fail(DSP_GPU_EINVAL, "fft_batch_f64: column length 2^%d", log2n);
+}
+// ... and `mats` matrices [other][2^log2n], transforms along the rows, written transposed
+int rows_t64(const c64 *in, c64 *out, int log2n, size_t mats, unsigned other, int direction, hipStream_t s) {
+    switch (log2n) {
+#define D64_CASE(K) \
+    case K: return launch_tile<K, F64_ROWS_T>(in, out, mats, direction, 0, 1, other, s);
+        D64_CASE(4) D64_CASE(5) D64_CASE(6) D64_CASE(7) D64_CASE(8) D64_CASE(9)
 #undef D64_CASE
     }
     return fail(DSP_GPU_EINVAL, "fft_batch_f64: row length 2^%d", log2n);
@@ -315,6 +392,13 @@ int launch_fft_batch_f64(const double *in_d, double *out_d, int log2n, size_t ba
     void *scratch_v = nullptr;
     if (int rc = workspace(WS_SCRATCH_A, batch * n * sizeof(c64), &scratch_v)) return rc;
     c64 *scratch = static_cast<c64 *>(scratch_v);
+    if (log2n <= 18) {
+        // two passes, the transposes folded into the tiles' loads and stores: x[n1][n2] -> over n1 down the columns, times
+        // W_N^{n2 k1} -> scratch[k1][n2] -> over n2 along the rows, written transposed -> out[k2][k1] = X[k1 + N1 k2].
+        // Pass 1 has consumed `in` before pass 2 writes `out`, so in == out needs nothing extra.
+        if (int rc = cols64(in, scratch, l1, batch, static_cast<unsigned>(n2), direction, log2n, s)) return rc;
+        return rows_t64(scratch, out, l2, batch, static_cast<unsigned>(n1), direction, s);
+    }
     // x[n1][n2]: transpose, transform over n1 (rows of the transposed matrix) with the twiddle W_N^{n2 k1} on the way out,
     // transpose, transform over n2, transpose: X[k2][k1] = X[k1 + N1 k2].  a and b alternate so that the last hop lands
     // in `out`; in place, the first hop goes to scratch and a copy finishes the chain.

@@ -64,7 +64,7 @@ def test_oracle_parity_every_length(ops, orc, dev, log2n):
     assert torch.equal(buf, ops.fft0_f64(xd))
 
 
-@pytest.mark.parametrize("log2n,batch", [(12, 4096), (22, 3), (24, 1)])
+@pytest.mark.parametrize("log2n,batch", [(12, 4096), (13, 517), (16, 700), (18, 67), (22, 3), (24, 1)])
 def test_properties_at_size(ops, dev, log2n, batch):
     """Round trip = N x, Parseval, an exact-bin tone and linearity at sizes the oracle does not reach in seconds."""
     import torch
