@@ -280,6 +280,8 @@ def biquad_swept(x, fc, bandwidth: float, kind: str = "bandpass", state=None, ou
     channels = int(np.prod(x.shape[:-1])) if x.ndim > 1 else 1
     if _is_torch(fc) != _is_torch(x):
         raise capi.DspGpuError(capi.EINVAL, "fc must live where x lives")
+    if _is_torch(fc) and fc.device != x.device:
+        raise capi.DspGpuError(capi.EINVAL, "fc must be on x's device")
     fc, pfc, _ = _prep(fc, np.float32, "float32")
     if tuple(fc.shape) == tuple(x.shape):
         stride = n
