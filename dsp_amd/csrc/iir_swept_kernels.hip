@@ -39,13 +39,12 @@ struct SweptState {
 // (coefficients.h:172-182), in the reference's own order of operations.  r = 1 - 3*BW and rr = r*r are the same for
 // every sample and come from the host.
 template <int KIND>
-DSP_DEV float swept_apply(float sample, double c, double r, double rr, SweptState &st) {
+DSP_DEV void swept_design(double c, double r, double rr, double &a0, double &a1, double &a2, double &b1) {
     // Doubling is exact, so 2*r*c == r*(2c), 2*(k-r)*c == (k-r)*(2c) and -2*k*c == -(k*(2c)) bit for bit: 2c is formed
     // once.  Everything else is the reference's expression, operation for operation.
     const double c2 = c + c;
-    const double b1 = r * c2;                       // 2 * R * cos2pif
+    b1 = r * c2;                                    // 2 * R * cos2pif
     const double k = (1 - b1 + rr) / (2 - c2);      // (1 - 2*R*cos2pif + R*R) / (2 - 2*cos2pif)
-    double a0, a1, a2;
     if (KIND == 0) {
         a0 = 1 - k;
         a1 = (k - r) * c2;                          // 2 * (K - R) * cos2pif
@@ -55,7 +54,10 @@ DSP_DEV float swept_apply(float sample, double c, double r, double rr, SweptStat
         a1 = -(k * c2);                             // -2 * K * cos2pif
         a2 = k;
     }
-    const double b2 = -rr;
+}
+
+// coefficients.h:172-182 with c0 = 1, d0 = 0 (what both designers leave, :70-71)
+DSP_DEV float swept_biquad(float sample, double a0, double a1, double a2, double b1, double b2, SweptState &st) {
     const double s = static_cast<double>(sample);
     double y = a0 * s + a1 * st.x1 + a2 * st.x2;
     y += b1 * st.y1 + b2 * st.y2;
@@ -63,7 +65,14 @@ DSP_DEV float swept_apply(float sample, double c, double r, double rr, SweptStat
     st.x1 = s;
     st.y2 = st.y1;
     st.y1 = y;
-    return static_cast<float>(y);  // c0 = 1, d0 = 0: what both designers leave (coefficients.h:70-71)
+    return static_cast<float>(y);
+}
+
+template <int KIND>
+DSP_DEV float swept_apply(float sample, double c, double r, double rr, SweptState &st) {
+    double a0, a1, a2, b1;
+    swept_design<KIND>(c, r, rr, a0, a1, a2, b1);
+    return swept_biquad(sample, a0, a1, a2, b1, -rr, st);
 }
 
 template <int KIND>
@@ -245,6 +254,121 @@ __global__ __launch_bounds__(kWave) void biquad_swept_kernel(const float *__rest
     }
 }
 
+// ONE sweep for all channels (fc_stride == 0): the design of a sample is the same in every lane, so it is done once per
+// WAVE and sample instead of once per lane and sample -- lane i of the wave designs sample t0 + i of the tile and leaves
+// {a0, a1, a2, b1} in LDS, from where the recursion reads them back as broadcasts (every lane the same address).  What
+// is left per lane and sample is the BiQuad step itself, and the kernel is bound by its 8 B/sample of HBM traffic.
+// Bit-identical to the per-lane design: it is the same function on the same value.  Rows of 128 samples as in
+// iir_batch_kernel (512-byte segments; 64-sample rows stop at the 4.4 TB/s of 256-byte segments: 1.93 against 1.6 ms),
+// two designs per lane and tile.
+template <int KIND, bool ALIGNED>
+__global__ __launch_bounds__(kWave) void biquad_swept_shared_kernel(const float *__restrict__ x, const float *__restrict__ fc,
+                                                                     float *__restrict__ y, size_t channels, size_t n, double r,
+                                                                     double rr, double *__restrict__ state, size_t groups,
+                                                                     size_t chunk) {
+    constexpr int T = 2 * kWave, kPerLane = T / kWave;
+    using S = SweptShape<T>;
+    __shared__ __attribute__((aligned(16))) float xt[kWave * S::kPad];
+    __shared__ __attribute__((aligned(16))) double co[T * 4];
+    const int lane = threadIdx.x;
+    const size_t group = xcd_tile_of(blockIdx.x, chunk);
+    if (group >= groups) return;
+    const size_t ch0 = group * kWave;
+    const size_t ch = ch0 + lane;
+    const bool live = ch < channels;
+
+    SweptState st{0.0, 0.0, 0.0, 0.0};
+    if (live && state) {
+        st.x1 = state[ch * 4 + 0];
+        st.x2 = state[ch * 4 + 1];
+        st.y1 = state[ch * 4 + 2];
+        st.y2 = state[ch * 4 + 3];
+    }
+    const double b2 = -rr;
+    const size_t ntiles = (n + T - 1) / T;
+    float4 px[S::kIters];
+    swept_load<T, ALIGNED>(x, n, channels, n, ch0, 0, lane, px);
+    float pf[kPerLane];
+#pragma unroll
+    for (int j = 0; j < kPerLane; ++j)  // past the end: any harmless frequency, never used
+        pf[j] = static_cast<size_t>(lane + kWave * j) < n ? fc[lane + kWave * j] : 0.25f;
+    for (size_t tl = 0; tl < ntiles; ++tl) {
+        const size_t t0 = tl * T;
+        swept_stage<T>(xt, lane, px);
+#pragma unroll
+        for (int j = 0; j < kPerLane; ++j) {
+            double a0, a1, a2, b1;
+            swept_design<KIND>(swept_cos(pf[j]), r, rr, a0, a1, a2, b1);
+            *reinterpret_cast<double2 *>(co + (lane + kWave * j) * 4) = make_double2(a0, a1);
+            *reinterpret_cast<double2 *>(co + (lane + kWave * j) * 4 + 2) = make_double2(a2, b1);
+        }
+        __syncthreads();
+        if (tl + 1 < ntiles) {
+            swept_load<T, ALIGNED>(x, n, channels, n, ch0, t0 + T, lane, px);
+#pragma unroll
+            for (int j = 0; j < kPerLane; ++j) pf[j] = t0 + T + lane + kWave * j < n ? fc[t0 + T + lane + kWave * j] : 0.25f;
+        }
+        if (live) {
+            float *xr = xt + lane * S::kPad;
+            const int count = t0 + T <= n ? T : static_cast<int>(n - t0);
+            if (count == T) {
+#pragma unroll 4
+                for (int i = 0; i < T; i += 4) {
+                    float4 q = *reinterpret_cast<const float4 *>(xr + i);
+                    float *e = reinterpret_cast<float *>(&q);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const double2 c01 = *reinterpret_cast<const double2 *>(co + (i + k) * 4);
+                        const double2 c23 = *reinterpret_cast<const double2 *>(co + (i + k) * 4 + 2);
+                        e[k] = swept_biquad(e[k], c01.x, c01.y, c23.x, c23.y, b2, st);
+                    }
+                    *reinterpret_cast<float4 *>(xr + i) = q;
+                }
+            } else {
+#pragma unroll 1
+                for (int i = 0; i < count; ++i) xr[i] = swept_biquad(xr[i], co[i * 4], co[i * 4 + 1], co[i * 4 + 2], co[i * 4 + 3], b2, st);
+            }
+        }
+        __syncthreads();
+        if (ALIGNED && ch0 + kWave <= channels && t0 + T <= n) {
+            const float *src = xt + (lane / S::kLanesPerRow) * S::kPad + (lane % S::kLanesPerRow) * 4;
+            float *p = y + (ch0 + lane / S::kLanesPerRow) * n + t0 + (lane % S::kLanesPerRow) * 4;
+            const size_t step = S::kRowsPerIter * n;
+#pragma unroll
+            for (int it = 0; it < S::kIters; ++it) {
+                const float4 q = *reinterpret_cast<const float4 *>(src + it * S::kRowsPerIter * S::kPad);
+                store_stream_f4(p + it * step, q.x, q.y, q.z, q.w);
+            }
+            __syncthreads();
+            continue;
+        }
+#pragma unroll
+        for (int it = 0; it < S::kIters; ++it) {
+            const size_t c = ch0 + it * S::kRowsPerIter + lane / S::kLanesPerRow;
+            const size_t g = t0 + (lane % S::kLanesPerRow) * 4;
+            if (c >= channels || g >= n) continue;
+            const float *src = xt + (it * S::kRowsPerIter + lane / S::kLanesPerRow) * S::kPad + (lane % S::kLanesPerRow) * 4;
+            float *p = y + c * n + g;
+            if (ALIGNED && g + 3 < n) {
+                const float4 q = *reinterpret_cast<const float4 *>(src);
+                store_stream_f4(p, q.x, q.y, q.z, q.w);
+            } else {
+                p[0] = src[0];
+                if (g + 1 < n) p[1] = src[1];
+                if (g + 2 < n) p[2] = src[2];
+                if (g + 3 < n) p[3] = src[3];
+            }
+        }
+        __syncthreads();
+    }
+    if (live && state) {
+        state[ch * 4 + 0] = st.x1;
+        state[ch * 4 + 1] = st.x2;
+        state[ch * 4 + 2] = st.y1;
+        state[ch * 4 + 3] = st.y2;
+    }
+}
+
 template <int KIND, bool ALIGNED>
 int swept_dispatch(const float *x, const float *fc, float *y, size_t channels, size_t n, size_t fc_stride, double bw,
                    double *state, hipStream_t s) {
@@ -256,6 +380,11 @@ int swept_dispatch(const float *x, const float *fc, float *y, size_t channels, s
     const size_t chunk = (groups + 7) / 8;
     if (8 * chunk > 0x7fffffffull) return fail(DSP_GPU_EUNSUPPORTED, "swept biquad: too many channels");
     const double r = 1 - 3 * bw;  // recursive_filters.h:168
+    if (fc_stride == 0) {
+        hipLaunchKernelGGL((biquad_swept_shared_kernel<KIND, ALIGNED>), dim3(static_cast<unsigned>(8 * chunk)), dim3(kWave), 0, s,
+                           x, fc, y, channels, n, r, r * r, state, groups, chunk);
+        return check_launch("biquad_swept_shared_kernel");
+    }
     hipLaunchKernelGGL((biquad_swept_kernel<KIND, T, ALIGNED>), dim3(static_cast<unsigned>(8 * chunk)), dim3(kWave), 0, s,
                        x, fc, y, channels, n, fc_stride, r, r * r, state, groups, chunk);
     return check_launch("biquad_swept_kernel");

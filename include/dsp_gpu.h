@@ -215,8 +215,9 @@ int dsp_gpu_iir_multi(const float *x, float *y, size_t channels, size_t n, const
  * second argument (fraction of the sample rate).  `state`: [channels][4] doubles {x1, x2, y1, y2} -- the BiQuad's
  * members (coefficients.h:52-68) -- read before, written after, may be NULL (= from rest); it lets a long run be fed in
  * blocks (blocked == unblocked bit for bit).  y == x (and y == fc when fc_stride == n) is in place.  One lane per
- * channel: tens of thousands of channels fill the chip.  Bound by double-precision arithmetic (~110 instructions per
- * sample), not by its 12 B/sample of traffic.
+ * channel: tens of thousands of channels fill the chip.  With one sweep per channel the kernel is bound by
+ * double-precision arithmetic (~60 instructions per sample), not by its 12 B/sample of traffic; a shared sweep is
+ * designed once per sample instead of once per channel and sample, and runs at the rate of dsp_gpu_iir's BATCH kernel.
  */
 #define DSP_GPU_SWEPT_BANDPASS 0
 #define DSP_GPU_SWEPT_BANDREJECT 1
