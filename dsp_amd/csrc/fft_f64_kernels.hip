@@ -8,11 +8,14 @@
 //               32 B of HBM traffic per point: bound by HBM like its fp32 sibling (fp64 FMA rate is not the limit).
 //   N <= 2^18   N = N1*N2, both <= 512: two passes of the same kernel, the transposes folded into its loads and stores
 //               (a tile of 4096/N1 adjacent columns, then a tile of 4096/N2 adjacent rows written transposed): 64 B/point.
-//   N <= 2^24   N = N1*N2, both <= 4096, Bailey's form with explicit transposes:
+//   N <= 2^24   N = N1*N2*N3, each 2^6 .. 2^8: three passes of that kernel (columns over n1, columns over n2 inside every
+//               row k1, rows over n3 written as [k3][k2][k1]): 96 B/point.
+//   DSP_GPU_F64_TRANSPOSES=1 (A/B partner, the first form of this route): N = N1*N2, both <= 4096, explicit transposes:
 //               [N1][N2] -T-> [N2][N1] -rows N1, x W_N^{n2 k1}-> -T-> [N1][N2] -rows N2-> -T-> X[k1 + N1 k2]
 //               five passes of 32 B per point (the twiddle rides the first row pass's stores).  Plain and correct rather
 //               than fast: this is the widening route, the fused column passes of the fp32 path are not repeated here.
 #include <algorithm>
+#include <cstdlib>
 
 #include "common.h"
 
@@ -178,13 +181,15 @@ D64_DEV void exchange64(c64 (&r)[kP64], c64 *lds, int lt, int base) {
 //      F64_COLS    `batch` matrices [N][other]: the tile's transforms are 4096/N adjacent COLUMNS, read and written in
 //                  place of one another through the LDS image so that HBM sees runs of 4096/N elements; the twiddle row
 //                  is the column index (pass 1 of the two-pass route: over n1, times W^{n2 k1})
-//      F64_ROWS_T  `batch` matrices [other][N]: the tile's transforms are 4096/N adjacent ROWS, element k of row r goes to
-//                  out[k][r] (pass 2: over n2, X[k1 + N1 k2] lands at [k2][k1]); in != out
+//      F64_ROWS_T  `batch` arrays [other][groups][N]: the tile's transforms are the rows (r, g) of 4096/N adjacent r at one g,
+//                  element k of row (r, g) goes to out[k][g][r] (the last pass: groups == 1 is the plain transposed
+//                  store of the two-pass route, X[k1 + N1 k2] at [k2][k1]; with groups == N2 the three-pass route's
+//                  X[k1 + N1 (k2 + N2 k3)] at [k3][k2][k1]); in != out
 enum F64Mode { F64_ROWS = 0, F64_COLS = 1, F64_ROWS_T = 2 };
 
 template <int LOG2N, int SIGN, int MODE>
 __global__ __launch_bounds__(kT64) void fft64_tile_kernel(const c64 *in, c64 *out, size_t batch, int tw_log2, unsigned tw_rows,
-                                                          unsigned other) {
+                                                          unsigned other, unsigned groups) {
     constexpr int N = 1 << LOG2N, T = N / kP64, PER_TILE = kTile64 / N;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     c64 *lds = reinterpret_cast<c64 *>(lds_raw);
@@ -194,15 +199,18 @@ __global__ __launch_bounds__(kT64) void fft64_tile_kernel(const c64 *in, c64 *ou
     const c64 *mat_in = in;
     c64 *mat_out = out;
     unsigned first = 0;  // first column (F64_COLS) / first row (F64_ROWS_T) of the tile inside its matrix
+    unsigned grp = 0;    // F64_ROWS_T: the tile's g
     if constexpr (MODE == F64_ROWS) {
         q = static_cast<size_t>(blockIdx.x) * PER_TILE + xf;
         live = q < batch;
     } else {
-        const unsigned tiles = other / PER_TILE;  // the launcher guarantees other % PER_TILE == 0
+        const unsigned tiles = other / PER_TILE * groups;  // the launcher guarantees other % PER_TILE == 0
         const size_t m = blockIdx.x / tiles;
-        first = (blockIdx.x % tiles) * PER_TILE;
-        mat_in = in + m * static_cast<size_t>(N) * other;
-        mat_out = out + m * static_cast<size_t>(N) * other;
+        const unsigned t = blockIdx.x % tiles;
+        first = (t / groups) * PER_TILE;
+        grp = t % groups;
+        mat_in = in + m * static_cast<size_t>(N) * other * groups;
+        mat_out = out + m * static_cast<size_t>(N) * other * groups;
         q = first + xf;
     }
     c64 r[kP64];
@@ -217,7 +225,7 @@ __global__ __launch_bounds__(kT64) void fft64_tile_kernel(const c64 *in, c64 *ou
         for (int m = 0; m < kP64; ++m) r[m] = lds[padded64(base + lt + T * m)];
         __syncthreads();
     } else if (live) {
-        const c64 *src = (MODE == F64_ROWS ? in + q * N : mat_in + static_cast<size_t>(first + xf) * N) + lt;
+        const c64 *src = (MODE == F64_ROWS ? in + q * N : mat_in + (static_cast<size_t>(first + xf) * groups + grp) * N) + lt;
 #pragma unroll
         for (int m = 0; m < kP64; ++m) r[m] = src[T * m];
     } else {
@@ -262,7 +270,8 @@ __global__ __launch_bounds__(kT64) void fft64_tile_kernel(const c64 *in, c64 *ou
 #pragma unroll
         for (int i = 0; i < kP64; ++i) {
             const int idx = tid + kT64 * i, c = idx % PER_TILE, e = idx / PER_TILE;
-            mat_out[static_cast<size_t>(e) * other + first + c] = lds[padded64(c * N + e)];
+            const size_t row = MODE == F64_COLS ? static_cast<size_t>(e) : static_cast<size_t>(e) * groups + grp;
+            mat_out[row * other + first + c] = lds[padded64(c * N + e)];
         }
     }
 }
@@ -307,21 +316,22 @@ __global__ __launch_bounds__(kT64) void transpose64_kernel(const c64 *__restrict
 
 template <int LOG2N, int MODE>
 int launch_tile(const c64 *in, c64 *out, size_t batch, int direction, int tw_log2, unsigned tw_rows, unsigned other,
-                hipStream_t s) {
+                unsigned groups, hipStream_t s) {
     constexpr size_t per_tile = kTile64 >> LOG2N;
     size_t blocks;
     if (MODE == F64_ROWS) {
         blocks = (batch + per_tile - 1) / per_tile;
     } else {
         if (other % per_tile != 0) return fail(DSP_GPU_EINVAL, "fft64_tile_kernel: %u is not a multiple of the tile's %zu", other, per_tile);
-        blocks = batch * (other / per_tile);
+        blocks = batch * (other / per_tile) * groups;
     }
     if (blocks > 0x7fffffffull) return fail(DSP_GPU_EUNSUPPORTED, "fft_batch_f64: batch too large for one launch");
     auto kf = fft64_tile_kernel<LOG2N, +1, MODE>;
     auto ki = fft64_tile_kernel<LOG2N, -1, MODE>;
     auto kern = direction == DSP_GPU_FORWARD ? kf : ki;
     if (int rc = allow_full_lds(reinterpret_cast<const void *>(kern))) return rc;
-    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks)), dim3(kT64), kLds64Bytes, s, in, out, batch, tw_log2, tw_rows, other);
+    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks)), dim3(kT64), kLds64Bytes, s, in, out, batch, tw_log2, tw_rows, other,
+                       groups);
     return check_launch("fft64_tile_kernel");
 }
 
@@ -342,7 +352,7 @@ int rows64(const c64 *in, c64 *out, int log2n, size_t batch, int direction, int 
     case 2: return launch_tiny<2>(in, out, batch, direction, s);
     case 3: return launch_tiny<3>(in, out, batch, direction, s);
 #define D64_CASE(K) \
-    case K: return launch_tile<K, F64_ROWS>(in, out, batch, direction, tw_log2, tw_rows, 0, s);
+    case K: return launch_tile<K, F64_ROWS>(in, out, batch, direction, tw_log2, tw_rows, 0, 1, s);
         D64_CASE(4) D64_CASE(5) D64_CASE(6) D64_CASE(7) D64_CASE(8) D64_CASE(9) D64_CASE(10) D64_CASE(11) D64_CASE(12)
 #undef D64_CASE
     }
@@ -354,17 +364,17 @@ int rows64(const c64 *in, c64 *out, int log2n, size_t batch, int direction, int 
 int cols64(const c64 *in, c64 *out, int log2n, size_t mats, unsigned other, int direction, int tw_log2, hipStream_t s) {
     switch (log2n) {
 #define D64_CASE(K) \
-    case K: return launch_tile<K, F64_COLS>(in, out, mats, direction, tw_log2, other, other, s);
+    case K: return launch_tile<K, F64_COLS>(in, out, mats, direction, tw_log2, other, other, 1, s);
         D64_CASE(4) D64_CASE(5) D64_CASE(6) D64_CASE(7) D64_CASE(8) D64_CASE(9)
 #undef D64_CASE
     }
     return fail(DSP_GPU_EINVAL, "fft_batch_f64: column length 2^%d", log2n);
 }
-// ... and `mats` matrices [other][2^log2n], transforms along the rows, written transposed
-int rows_t64(const c64 *in, c64 *out, int log2n, size_t mats, unsigned other, int direction, hipStream_t s) {
+// ... and `mats` arrays [other][groups][2^log2n], transforms along the rows, written as [k][groups][other]
+int rows_t64(const c64 *in, c64 *out, int log2n, size_t mats, unsigned other, unsigned groups, int direction, hipStream_t s) {
     switch (log2n) {
 #define D64_CASE(K) \
-    case K: return launch_tile<K, F64_ROWS_T>(in, out, mats, direction, 0, 1, other, s);
+    case K: return launch_tile<K, F64_ROWS_T>(in, out, mats, direction, 0, 1, other, groups, s);
         D64_CASE(4) D64_CASE(5) D64_CASE(6) D64_CASE(7) D64_CASE(8) D64_CASE(9)
 #undef D64_CASE
     }
@@ -392,12 +402,26 @@ int launch_fft_batch_f64(const double *in_d, double *out_d, int log2n, size_t ba
     void *scratch_v = nullptr;
     if (int rc = workspace(WS_SCRATCH_A, batch * n * sizeof(c64), &scratch_v)) return rc;
     c64 *scratch = static_cast<c64 *>(scratch_v);
-    if (log2n <= 18) {
+    static const bool with_transposes = [] {  // DSP_GPU_F64_TRANSPOSES=1: the five-pass form below (A/B partner)
+        const char *e = std::getenv("DSP_GPU_F64_TRANSPOSES");
+        return e && e[0] == '1';
+    }();
+    if (!with_transposes && log2n <= 18) {
         // two passes, the transposes folded into the tiles' loads and stores: x[n1][n2] -> over n1 down the columns, times
         // W_N^{n2 k1} -> scratch[k1][n2] -> over n2 along the rows, written transposed -> out[k2][k1] = X[k1 + N1 k2].
         // Pass 1 has consumed `in` before pass 2 writes `out`, so in == out needs nothing extra.
         if (int rc = cols64(in, scratch, l1, batch, static_cast<unsigned>(n2), direction, log2n, s)) return rc;
-        return rows_t64(scratch, out, l2, batch, static_cast<unsigned>(n1), direction, s);
+        return rows_t64(scratch, out, l2, batch, static_cast<unsigned>(n1), 1, direction, s);
+    }
+    if (!with_transposes) {
+        // three passes, N = N1 * N2 * N3 (each 2^6 .. 2^8 here): x[n1][m], m = n2 N3 + n3.  Down the columns over n1,
+        // times W_N^{m k1} -> scratch[k1][n2][n3]; inside every row k1, down the columns over n2, times W_M^{n3 k2}, in
+        // place -> scratch[k1][k2][n3]; along the rows over n3, written as out[k3][k2][k1] = X[k1 + N1 (k2 + N2 k3)].
+        const int t3 = log2n / 3, t2 = (log2n - t3) / 2, t1 = log2n - t3 - t2;
+        const size_t m = static_cast<size_t>(1) << (t2 + t3);
+        if (int rc = cols64(in, scratch, t1, batch, static_cast<unsigned>(m), direction, log2n, s)) return rc;
+        if (int rc = cols64(scratch, scratch, t2, batch << t1, 1u << t3, direction, t2 + t3, s)) return rc;
+        return rows_t64(scratch, out, t3, batch, 1u << t1, 1u << t2, direction, s);
     }
     // x[n1][n2]: transpose, transform over n1 (rows of the transposed matrix) with the twiddle W_N^{n2 k1} on the way out,
     // transpose, transform over n2, transpose: X[k2][k1] = X[k1 + N1 k2].  a and b alternate so that the last hop lands

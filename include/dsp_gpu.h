@@ -84,9 +84,9 @@ int dsp_gpu_fft_batch(const void *in, void *out, int log2n, size_t batch, int di
  * The same transform in the reference's own sample type: dsp::fft0<type>(const std::complex<double>*,
  * std::complex<double>*, int log2n) (fft.h:31-32 declares fft0 for double only).  Interleaved (re,im) double pairs,
  * arithmetic in double throughout (twiddles from sincospi on exact dyadic angles), natural-order output, unnormalised,
- * in == out allowed.  1 <= log2n <= 24: one HBM pass up to 4096 points, two up to 2^18 (the transposes folded into the
- * tiles' loads and stores), five above (Bailey's form with explicit transposes), both through a library workspace --
- * the widening route, not the benchmarked one; DSP_GPU_EINVAL beyond 2^24.
+ * in == out allowed.  1 <= log2n <= 24: one HBM pass up to 4096 points, two up to 2^18, three above (the transposes
+ * folded into the tiles' loads and stores), through a library workspace -- the widening route, not the benchmarked
+ * one; DSP_GPU_EINVAL beyond 2^24.
  */
 int dsp_gpu_fft_batch_f64(const void *in, void *out, int log2n, size_t batch, int direction, int mem,
                           void *stream);
