@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="fft",
                     choices=["fft", "fir_direct", "fir_direct_valu", "fir_os", "iir_batch", "iir_scan", "mavg", "fft_dist",
-                             "fft_32k", "fft_real_64k", "fft_f64", "biquad_swept"])
+                             "fft_32k", "fft_real_64k", "fft_f64", "biquad_swept", "biquad_swept_shared"])
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: every GPU gets the full per-GPU batch; strong: the one-GPU batch is channel-sharded")
     ap.add_argument("--dist-exchange", default="torch", choices=["torch", "rccl"],
@@ -180,8 +180,9 @@ def make_iir(torch, dev, ops, rank, mode):
     return step, channels * n, meta
 
 
-def make_swept(torch, dev, ops, rank):
-    """the band-pass retuned every sample (eval/signals/wind_generator.h:150-167), a batch of voices."""
+def make_swept(torch, dev, ops, rank, shared=False):
+    """SURVEY.md 8f-4: the band-pass retuned every sample (eval/signals/wind_generator.h:150-167), a batch of voices;
+    shared: all voices follow ONE sweep (designed once per sample, 8 B/sample)."""
     channels, n = _share(262144), 4096
     g = torch.Generator(device=dev).manual_seed(160 + rank)
     x = torch.randn(channels, n, device=dev, generator=g)
@@ -192,16 +193,21 @@ def make_swept(torch, dev, ops, rank):
     fc = ((1000.0 + 1000.0 * (0.5 + 0.5 * torch.sin(rate * t + phase))) / 44100.0).contiguous()
     y = torch.empty_like(x)
     bw = 60.0 / 44100.0
+    if shared:
+        fc = fc[0].contiguous()
 
     def step():
         ops.biquad_swept(x, fc, bw, out=y)
 
-    meta = dict(metric="biquad_swept_throughput", unit="GSamples/s", dtype="f64", bound="hbm", alg_per_unit=12.0,
-                alg_unit="bytes/sample (x and fc read, y written); the kernel is bound by its ~70 fp64 instructions per sample "
+    meta = dict(metric="biquad_swept_throughput", unit="GSamples/s", dtype="f64", bound="hbm",
+                alg_per_unit=8.0 if shared else 12.0,
+                alg_unit="bytes/sample (x read, y written; the one sweep is read once per 64 voices)" if shared else
+                         "bytes/sample (x and fc read, y written); the kernel is bound by its ~60 fp64 instructions per sample "
                          "before it is by HBM",
-                kernel="biquad_swept_kernel",
+                kernel="biquad_swept_shared_kernel" if shared else "biquad_swept_kernel",
                 config={"workload": "band-pass redesigned from fc[t] before every step (wind_generator.h:150-167), "
-                                    "262,144 voices x 4,096 samples fp32, one sweep per voice, per GPU",
+                                    "262,144 voices x 4,096 samples fp32, " +
+                                    ("one sweep for all voices" if shared else "one sweep per voice") + ", per GPU",
                         "channels": channels, "n": n})
     return step, channels * n, meta
 
@@ -298,7 +304,7 @@ def _cpu_sample(workload, seconds, seed):
         x = rng.standard_normal(1 << 22).astype(np.float32)
         call, per_call, unit = (lambda: lib.moving_average(x, 511)), x.size, "GSamples/s"
         sample = "MovingAverageFilter{{511}} (filter.h:81-101), float, {calls} 2^22-sample slices"
-    elif workload == "biquad_swept":
+    elif workload in ("biquad_swept", "biquad_swept_shared"):
         x = rng.standard_normal(1 << 20).astype(np.float32)
         fc = ((1000.0 + 1000.0 * (0.5 + 0.5 * np.sin(0.01 * np.arange(x.size)))) / 44100.0).astype(np.float32)
         call, per_call, unit = (lambda: lib.biquad_swept(x, fc, 60.0 / 44100.0)), x.size, "GSamples/s"
@@ -369,8 +375,8 @@ def main():
                                                                  "fir_os": "overlap_save"}[workload])
         elif workload == "mavg":
             step, units, meta = make_mavg(torch, dev, ops, rank)
-        elif workload == "biquad_swept":
-            step, units, meta = make_swept(torch, dev, ops, rank)
+        elif workload in ("biquad_swept", "biquad_swept_shared"):
+            step, units, meta = make_swept(torch, dev, ops, rank, shared=workload.endswith("shared"))
         else:
             step, units, meta = make_iir(torch, dev, ops, rank, "batch" if workload == "iir_batch" else "scan")
         for _ in range(warmup):

@@ -12,7 +12,8 @@ SRC = os.path.join(ROOT, "gpurun_out", f"prof_{ROUND}")
 KERNEL = {"fft": "fft_lds_kernel", "fir_direct": "fir_direct_kernel", "fir_os": "fir_os_wave_kernel",
           "mavg": "moving_average_kernel", "iir_batch": "iir_batch_kernel", "iir_scan": "iir_scan_kernel",
           "fft_dist": "fft_column_kernel", "fft_32k": "fft_plane_kernel", "fft_real_64k": "fft_plane_kernel",
-          "fft_f64": "fft64_tile_kernel", "biquad_swept": "biquad_swept_kernel"}
+          "fft_f64": "fft64_tile_kernel", "biquad_swept": "biquad_swept_kernel",
+          "biquad_swept_shared": "biquad_swept_shared_kernel"}
 tpath = os.path.join(ROOT, "profiles", "traffic.json")
 traffic = json.load(open(tpath)) if os.path.exists(tpath) else {}
 newest = lambda pat: sorted(glob.glob(pat, recursive=True), key=os.path.getmtime, reverse=True)
