@@ -206,7 +206,11 @@ __global__ __launch_bounds__(kWave) void biquad_swept_kernel(const float *__rest
                 for (int i = 0; i < T; i += 4) {
                     float4 q = *reinterpret_cast<const float4 *>(xr + i);
                     const float4 f = *reinterpret_cast<const float4 *>(fr + i);
+#ifdef SWEPT_ABLATE  // memory skeleton only (a build for measuring it, never the library's): loads, LDS, stores
+                    q.x += f.x; q.y += f.y; q.z += f.z; q.w += f.w;
+#else
                     q = swept_step4<KIND>(q, f, r, rr, st);
+#endif
                     *reinterpret_cast<float4 *>(xr + i) = q;
                 }
             } else {
@@ -374,8 +378,15 @@ int swept_dispatch(const float *x, const float *fc, float *y, size_t channels, s
                    double *state, hipStream_t s) {
     // 32-sample rows: 2 x 9 KB of LDS per one-wave workgroup, so eight of them fit a CU = two waves per SIMD, which this
     // arithmetic-bound kernel needs more than it needs long row segments (measured on 262,144 x 4,096, per-channel
-    // sweeps, at the time: 32-sample rows 3.33 ms, 64: 3.76 ms, 128: 7.6 ms -- two workgroups per CU and spills)
+    // sweeps, at the time: 32-sample rows 3.33 ms, 64: 3.76 ms, 128: 7.6 ms -- two workgroups per CU and spills).  As it
+    // stands the kernel runs at 0.95 of its own memory skeleton (2.93 against 2.77 ms with the arithmetic compiled out);
+    // the skeleton improves with the row length (64: 2.62 ms, 128: 2.12 ms) but the arithmetic then has one wave per SIMD
+    // or less to run on (64-sample rows, everything: 3.15 ms).
+#ifdef SWEPT_T  // other row lengths, for the same measurement (profiles/r02_biquad_swept_ablation.txt)
+    constexpr int T = SWEPT_T;
+#else
     constexpr int T = 32;
+#endif
     const size_t groups = (channels + kWave - 1) / kWave;
     const size_t chunk = (groups + 7) / 8;
     if (8 * chunk > 0x7fffffffull) return fail(DSP_GPU_EUNSUPPORTED, "swept biquad: too many channels");
