@@ -908,6 +908,8 @@ int scan_launch(const float *x, float *y, size_t channels, size_t n, const IirCo
     }();
     const unsigned per_xcd = wgs_per_cu ? std::min((ntiles + 7u) / 8u, 32u * wgs_per_cu) : (ntiles + 7u) / 8u;
     const dim3 grid(ntiles >= 64u ? 8u * per_xcd : ntiles, static_cast<unsigned>(channels));
+    // (capping the one-wave workgroups per CU with unused LDS, which helps iir_batch_kernel, costs the scan: 14 per CU
+    // 0.446 ms, 8 per CU 0.502, 4 per CU 0.641 on a box where the plain launch took 0.436-0.446)
     if (fused) {
         hipLaunchKernelGGL((iir_scan_kernel<P, SCAN_FUSED, ALIGNED, WIDE>), grid, dim3(kSt), 0, s, x, y, n, co, d_table,
                            state_in, state, nullptr, nullptr, ntiles, warm, levels, d_table + 18 * ms, 0);
@@ -1053,14 +1055,25 @@ int batch_dispatch(const float *x, float *y, size_t channels, size_t n, const Ii
     const size_t chunk = (groups + 7) / 8;
     if (8 * chunk > 0x7fffffffull) return fail(DSP_GPU_EUNSUPPORTED, "IIR batch: too many channels");
     const dim3 grid(static_cast<unsigned>(8 * chunk));
+    // Dynamic LDS nobody uses: it only lowers the number of workgroups a CU holds.  Up to four poles the recursion is
+    // cheap enough for TWO one-wave workgroups per CU to keep up with memory, and with 2 x 32 KB instead of 4 x 32 KB of
+    // tiles in flight per CU the memory system runs faster (the round's in-flight lesson):
+    // 262,144 x 4,096, 4 poles: 1.485 -> 1.375 ms (0.72 -> 0.78 of 8 TB/s); 3 per CU 0.70, 1 per CU 0.45.  From six
+    // poles on the arithmetic needs all four SIMDs (6 poles: 1.49 ms at four per CU, 1.68 at two).
+    // DSP_GPU_IIR_BATCH_LDS_PAD=<bytes> overrides (0 = four per CU).
+    static const int pad_env = [] {
+        const char *e = std::getenv("DSP_GPU_IIR_BATCH_LDS_PAD");
+        return e ? std::atoi(e) : -1;
+    }();
+    const unsigned pad = pad_env >= 0 ? static_cast<unsigned>(pad_env) : (P <= 4 ? 30000u : 0u);
     if constexpr (P <= 8) {
         if (pc) {
-            hipLaunchKernelGGL((iir_batch_kernel<P, ALIGNED, true>), grid, dim3(kWave), 0, s, x, y, channels, n, co, state,
+            hipLaunchKernelGGL((iir_batch_kernel<P, ALIGNED, true>), grid, dim3(kWave), pad, s, x, y, channels, n, co, state,
                                groups, chunk, co.poles, *pc);
             return check_launch("iir_batch_kernel<per-channel>");
         }
     }
-    hipLaunchKernelGGL((iir_batch_kernel<P, ALIGNED, false>), grid, dim3(kWave), 0, s, x, y, channels, n, co, state, groups,
+    hipLaunchKernelGGL((iir_batch_kernel<P, ALIGNED, false>), grid, dim3(kWave), pad, s, x, y, channels, n, co, state, groups,
                        chunk, co.poles, IirPerChannel{});
     return check_launch("iir_batch_kernel");
 }

@@ -392,6 +392,7 @@ int swept_dispatch(const float *x, const float *fc, float *y, size_t channels, s
     if (8 * chunk > 0x7fffffffull) return fail(DSP_GPU_EUNSUPPORTED, "swept biquad: too many channels");
     const double r = 1 - 3 * bw;  // recursive_filters.h:168
     if (fc_stride == 0) {
+        // (two workgroups per CU instead of four, which helps iir_batch_kernel, costs this one a third: 1.46 -> 2.14 ms)
         hipLaunchKernelGGL((biquad_swept_shared_kernel<KIND, ALIGNED>), dim3(static_cast<unsigned>(8 * chunk)), dim3(kWave), 0, s,
                            x, fc, y, channels, n, r, r * r, state, groups, chunk);
         return check_launch("biquad_swept_shared_kernel");
