@@ -117,7 +117,8 @@ DSP_DEV void run_row4(float *row, double (&xh)[P], double (&vh)[P], const C &co)
 // ---------------------------------------------------------------------------------------------
 // batch: one lane per channel
 // ---------------------------------------------------------------------------------------------
-constexpr int kBt = 128;         // samples per tile row: 512-byte row segments (256-byte ones cap a plain copy at 4.4 TB/s, scripts/copy_patterns3.hip)
+constexpr int kBt = 128;         // samples per tile row: 512-byte row segments (256-byte ones cap a plain copy at 4.4 TB/s, scripts/copy_patterns3.hip;
+                                 // 256-sample rows, two workgroups per CU by their own LDS: 0.745 against 0.77 of 8 TB/s)
 constexpr int kBtPad = kBt + 4;  // rows 16-byte aligned; lane stride 132 dwords: 16-byte row walks are conflict-free
 constexpr int kBtIters = kBt * kWave / (kWave * 4);  // float4 loads per lane per tile = 16
 
