@@ -683,6 +683,20 @@ __global__ __launch_bounds__(kThreads) void swap_halves_kernel(c32 *__restrict__
 }
 
 // ---- host-side dispatch ---------------------------------------------------------------------
+// DSP_GPU_FFT_ROW_WGS_PER_CU = 3 or 2 (default 4, what the 34 KB image allows): unused dynamic LDS that only lowers the
+// number of fft_lds_kernel workgroups a CU holds.  With fewer 32 KB tiles in flight per CU the memory system runs
+// faster once the chip has been busy for ~40 launches (65,536 x 4096, sustained: 4 per CU 0.719 ms = 0.745 of 8 TB/s,
+// 3 per CU 0.699 = 0.768, 2 per CU 0.675 = 0.795; every size from 32 points up gains alike), but in the first ~25
+// launches after idle -- which is what a short benchmark run times -- the order is the reverse (0.725 / 0.730 / 0.776 ms),
+// so the default stays at four and sustained pipelines can opt in.
+static unsigned row_lds_pad() {
+    static const unsigned pad = [] {
+        const char *e = getenv("DSP_GPU_FFT_ROW_WGS_PER_CU");
+        const int w = e ? atoi(e) : 4;
+        return w == 3 ? 8192u : (w == 2 ? 20480u : 0u);
+    }();
+    return pad;
+}
 template <int LOG2N, bool REAL_IN, bool SHIFTED>
 int launch_small(const void *in, c32 *out, size_t batch, size_t n_in, size_t in_stride, int direction,
                  hipStream_t s) {
@@ -693,10 +707,10 @@ int launch_small(const void *in, c32 *out, size_t batch, size_t n_in, size_t in_
         if (8 * chunk > 0x7fffffffull) return fail(DSP_GPU_EUNSUPPORTED, "batch too large for one launch");
         const dim3 grid(static_cast<unsigned>(8 * chunk));
         if (direction == DSP_GPU_FORWARD)
-            hipLaunchKernelGGL((fft_lds_kernel<LOG2N, +1, REAL_IN, SHIFTED>), grid, dim3(kThreads), 0, s, in, out, batch,
+            hipLaunchKernelGGL((fft_lds_kernel<LOG2N, +1, REAL_IN, SHIFTED>), grid, dim3(kThreads), row_lds_pad(), s, in, out, batch,
                                n_in, in_stride, tiles, chunk);
         else
-            hipLaunchKernelGGL((fft_lds_kernel<LOG2N, -1, REAL_IN, SHIFTED>), grid, dim3(kThreads), 0, s, in, out, batch,
+            hipLaunchKernelGGL((fft_lds_kernel<LOG2N, -1, REAL_IN, SHIFTED>), grid, dim3(kThreads), row_lds_pad(), s, in, out, batch,
                                n_in, in_stride, tiles, chunk);
     } else {
         const size_t blocks = (batch + kThreads - 1) / kThreads;
