@@ -99,6 +99,47 @@ def test_one_sweep_for_all_channels(ops, dev, orc):
     assert np.array_equal(got, each.cpu().numpy())  # the shared sweep is the same arithmetic
 
 
+@pytest.mark.parametrize("channels,n", [(1, 5), (70, 1001), (64, 128), (65, 257), (3, 4096)])
+def test_one_sweep_ragged_shapes_and_state(ops, dev, orc, channels, n):
+    """The shared-sweep kernel (coefficients designed once per wave and sample) on partial tiles, partial channel
+    groups, unaligned rows, with state in and out: the oracle, and the per-channel kernel bit for bit."""
+    import torch
+    rng = np.random.default_rng(channels * 31 + n)
+    x = rng.standard_normal((channels, n)).astype(np.float32)
+    fc = sweeps(rng, 1, n)[0]
+    s_in = rng.standard_normal((channels, 4)) * 0.1
+    s_orc = s_in.copy()
+    want = orc.biquad_swept(x, fc, BW, "bandreject", state=s_orc)
+    st = torch.from_numpy(s_in.copy()).to(dev)
+    xd = torch.from_numpy(x).to(dev)
+    got = ops.biquad_swept(xd, torch.from_numpy(fc).to(dev), BW, kind="bandreject", state=st)
+    close_enough(got.cpu().numpy(), want)
+    assert np.allclose(st.cpu().numpy(), s_orc, rtol=1e-9, atol=1e-12)
+    st2 = torch.from_numpy(s_in.copy()).to(dev)
+    each = ops.biquad_swept(xd, torch.from_numpy(np.broadcast_to(fc, x.shape).copy()).to(dev), BW, kind="bandreject", state=st2)
+    assert torch.equal(got, each) and torch.equal(st, st2)
+
+
+def test_misaligned_base_pointers(ops, dev, orc):
+    """x, fc and y that start 4 bytes off a 16-byte boundary (views into larger buffers) take the element-wise path."""
+    import torch
+    rng = np.random.default_rng(12)
+    ch, n = 66, 512
+    x = rng.standard_normal((ch, n)).astype(np.float32)
+    fc = sweeps(rng, ch, n)
+    bx = torch.zeros(ch * n + 1, device=dev)
+    bf = torch.zeros(ch * n + 1, device=dev)
+    by = torch.zeros(ch * n + 1, device=dev)
+    bx[1:] = torch.from_numpy(x).to(dev).flatten()
+    bf[1:] = torch.from_numpy(fc).to(dev).flatten()
+    xv, fv, yv = bx[1:].view(ch, n), bf[1:].view(ch, n), by[1:].view(ch, n)
+    assert xv.data_ptr() % 16 == 4
+    ops.biquad_swept(xv, fv, BW, out=yv)
+    close_enough(yv.cpu().numpy(), orc.biquad_swept(x, fc, BW))
+    ops.biquad_swept(xv, fv[0], BW, out=yv)  # one sweep for all, same misalignment
+    close_enough(yv.cpu().numpy(), orc.biquad_swept(x, fc[0], BW))
+
+
 def test_blocks_with_carried_state_are_bit_exact(ops, dev):
     """Fed in audio-callback sized blocks (256 frames, eval/signals/main.cpp) with the BiQuad's members carried,
     the output is the unblocked one bit for bit."""
