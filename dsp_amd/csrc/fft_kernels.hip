@@ -683,16 +683,17 @@ __global__ __launch_bounds__(kThreads) void swap_halves_kernel(c32 *__restrict__
 }
 
 // ---- host-side dispatch ---------------------------------------------------------------------
-// DSP_GPU_FFT_ROW_WGS_PER_CU = 3 or 2 (default 4, what the 34 KB image allows): unused dynamic LDS that only lowers the
-// number of fft_lds_kernel workgroups a CU holds.  With fewer 32 KB tiles in flight per CU the memory system runs
-// faster once the chip has been busy for ~40 launches (65,536 x 4096, sustained: 4 per CU 0.719 ms = 0.745 of 8 TB/s,
-// 3 per CU 0.699 = 0.768, 2 per CU 0.675 = 0.795; every size from 32 points up gains alike), but in the first ~25
-// launches after idle -- which is what a short benchmark run times -- the order is the reverse (0.725 / 0.730 / 0.776 ms),
-// so the default stays at four and sustained pipelines can opt in.
+// Workgroups of fft_lds_kernel per CU: the 34 KB image allows four; unused dynamic LDS lowers that to THREE (default) or
+// two (DSP_GPU_FFT_ROW_WGS_PER_CU=2; =4 restores the old launch).  With fewer 32 KB tiles in flight per CU the memory
+// system runs faster once the chip has been busy for ~40 launches -- 65,536 x 4096, sustained: four per CU 0.719 ms
+// = 0.745 of 8 TB/s, three 0.699 = 0.768, two 0.675 = 0.795, and every size from 32 points up gains alike -- but in the
+// first ~25 launches after idle the order is the reverse (0.725 / 0.730 / 0.776 ms).  Three per CU is the setting that
+// loses nothing cold (-0.5 %) and gains warm (+3 %); two is for pipelines that stay busy (DESIGN.md section 4.1,
+// profiles/r02_fft_wgs_per_cu.txt).
 static unsigned row_lds_pad() {
     static const unsigned pad = [] {
         const char *e = getenv("DSP_GPU_FFT_ROW_WGS_PER_CU");
-        const int w = e ? atoi(e) : 4;
+        const int w = e ? atoi(e) : 3;
         return w == 3 ? 8192u : (w == 2 ? 20480u : 0u);
     }();
     return pad;
