@@ -690,14 +690,16 @@ __global__ __launch_bounds__(kThreads) void swap_halves_kernel(c32 *__restrict__
 // first ~25 launches after idle the order is the reverse (0.725 / 0.730 / 0.776 ms).  Three per CU is the setting that
 // loses nothing cold (-0.5 %) and gains warm (+3 %); two is for pipelines that stay busy (DESIGN.md section 4.1,
 // profiles/r02_fft_wgs_per_cu.txt).
-static unsigned row_lds_pad() {
-    static const unsigned pad = [] {
+// Complex transforms of up to 256 points keep four (three reads 1.5 % slower there; real-input rows gain at every size).
+static unsigned row_lds_pad(int log2n, bool real_in) {
+    static const int forced = [] {
         const char *e = getenv("DSP_GPU_FFT_ROW_WGS_PER_CU");
-        const int w = e ? atoi(e) : 3;
-        return w == 3 ? 8192u : (w == 2 ? 20480u : 0u);
+        return e ? atoi(e) : 0;
     }();
-    return pad;
+    const int w = forced ? forced : ((log2n >= 9 || real_in) ? 3 : 4);
+    return w == 3 ? 8192u : (w == 2 ? 20480u : 0u);
 }
+
 template <int LOG2N, bool REAL_IN, bool SHIFTED>
 int launch_small(const void *in, c32 *out, size_t batch, size_t n_in, size_t in_stride, int direction,
                  hipStream_t s) {
@@ -708,10 +710,10 @@ int launch_small(const void *in, c32 *out, size_t batch, size_t n_in, size_t in_
         if (8 * chunk > 0x7fffffffull) return fail(DSP_GPU_EUNSUPPORTED, "batch too large for one launch");
         const dim3 grid(static_cast<unsigned>(8 * chunk));
         if (direction == DSP_GPU_FORWARD)
-            hipLaunchKernelGGL((fft_lds_kernel<LOG2N, +1, REAL_IN, SHIFTED>), grid, dim3(kThreads), row_lds_pad(), s, in, out, batch,
+            hipLaunchKernelGGL((fft_lds_kernel<LOG2N, +1, REAL_IN, SHIFTED>), grid, dim3(kThreads), row_lds_pad(LOG2N, REAL_IN), s, in, out, batch,
                                n_in, in_stride, tiles, chunk);
         else
-            hipLaunchKernelGGL((fft_lds_kernel<LOG2N, -1, REAL_IN, SHIFTED>), grid, dim3(kThreads), row_lds_pad(), s, in, out, batch,
+            hipLaunchKernelGGL((fft_lds_kernel<LOG2N, -1, REAL_IN, SHIFTED>), grid, dim3(kThreads), row_lds_pad(LOG2N, REAL_IN), s, in, out, batch,
                                n_in, in_stride, tiles, chunk);
     } else {
         const size_t blocks = (batch + kThreads - 1) / kThreads;
