@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the MI355X hot path (BASELINE.json metric), one JSON line on stdout.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload fft|fir_direct|fir_os|iir_batch|iir_scan|mavg]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload fft|fir_direct|fir_os|iir_batch|iir_scan|mavg|...]
 
 Default workload = BASELINE.json configs[1]: 65,536 x 4096-point complex fp32 FFT (FORWARD) of
 synthetic N(0,1) noise, inputs resident in HBM.  A "step" is one pass of the hot path over that
@@ -9,6 +9,11 @@ batch through the C ABI (dsp_gpu_fft_batch).  N > 1: launched by torch.distribut
 per GPU; channels are independent, so every rank owns its own batch of the same size (weak
 scaling, no data-path collective) and `value` = samples all ranks processed / max-over-ranks time.
 
+`secondary`    the default run also times the FIR / IIR / moving-average workloads BASELINE's metric names, each with
+               the same W warm-up and K timed steps between the same barriers.  They are timed BEFORE the headline
+               FFT (--headline-first: after it): the first memory-bound workload of a fresh process would be
+               timed while the chip is still ramping, the MFMA-bound direct FIR that goes first
+               does not care, and every figure of the line is then taken at sustained clocks.
 `roofline`     algorithmic bytes (or flops) of one launch / average launch time measured with
                HIP events recorded on the stream the launches go to, over the timed region.
 `cpu_baseline` the reference's own code (oracle/_ref, kind "reference") if that library
