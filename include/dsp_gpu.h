@@ -211,7 +211,7 @@ int dsp_gpu_iir_multi(const float *x, float *y, size_t channels, size_t n, const
  * multiply-adds; only cos() may differ from a CPU's in its last bit.  x, y: [channels][n] fp32.  fc: centre frequency
  * per sample as a fraction of the sample rate, in (0, 0.5], fp32 (the reference computes it in float,
  * wind_generator.h:157-158): [channels][n] with fc_stride == n, or ONE sweep [n] shared by all channels with
- * fc_stride == 0.  fc[t] == 0 divides by zero exactly as the reference does (K = NaN).  bandwidth: as the reference's
+ * fc_stride == 0.  fc[t] == 0 divides by zero exactly as the reference does (K = +inf; the outputs turn infinite, then NaN).  bandwidth: as the reference's
  * second argument (fraction of the sample rate).  `state`: [channels][4] doubles {x1, x2, y1, y2} -- the BiQuad's
  * members (coefficients.h:52-68) -- read before, written after, may be NULL (= from rest); it lets a long run be fed in
  * blocks (blocked == unblocked bit for bit).  y == x (and y == fc when fc_stride == n) is in place.  One lane per

@@ -222,6 +222,23 @@ def test_full_size_properties(ops, dev, orc):
     assert torch.equal(ops.biquad_swept(x * 0.5, fc, BW), y * 0.5)
 
 
+def test_zero_frequency_divides_by_zero_like_the_reference(ops, dev, orc):
+    """bandPassFilter(0, bw) divides by 2 - 2 cos(0) = 0 (recursive_filters.h:170): K = +inf, and the recursion turns infinite, then NaN,
+    from that sample on -- in the reference, in the oracle and here, at the same samples; other channels are untouched."""
+    import torch
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((3, 200)).astype(np.float32)
+    fc = sweeps(rng, 3, 200)
+    fc[1, 77] = 0.0
+    want = orc.biquad_swept(x, fc, BW)
+    got = ops.biquad_swept(torch.from_numpy(x).to(dev), torch.from_numpy(fc).to(dev), BW).cpu().numpy()
+    assert np.isfinite(want[1, :77]).all() and not np.isfinite(want[1, 77:]).any()
+    bad = ~np.isfinite(want)
+    assert np.array_equal(~np.isfinite(got), bad) and np.array_equal(got[bad], want[bad], equal_nan=True)  # same inf / NaN
+    close_enough(got[[0, 2]], want[[0, 2]])
+    close_enough(got[1, :77], want[1, :77])
+
+
 def test_errors(ops, dev):
     import torch
     from dsp_amd import capi
