@@ -16,7 +16,8 @@ OK, EINVAL, EHIP, ENOMEM, EUNSUPPORTED = 0, -1, -2, -3, -4
 FORWARD, INVERSE = 0, 1
 MEM_HOST, MEM_DEVICE = 0, 1
 CONV_AUTO, CONV_DIRECT, CONV_OVERLAP_SAVE, CONV_DIRECT_VALU = 0, 1, 2, 3
-IIR_AUTO, IIR_BATCH, IIR_SCAN = 0, 1, 2
+IIR_AUTO, IIR_BATCH, IIR_SCAN, IIR_BATCH_REF = 0, 1, 2, 3
+F32, F64 = 0, 1
 DIST_TRANSPOSED_OUT = 1
 DIST_SERIAL = 2
 
@@ -27,10 +28,14 @@ EXPORTS = (
     "dsp_gpu_fft_batch_noalloc",
     "dsp_gpu_fft_real_batch",
     "dsp_gpu_convolve",
+    "dsp_gpu_convolve_f64",
     "dsp_gpu_convolve_stream",
     "dsp_gpu_moving_average",
+    "dsp_gpu_moving_average_f64",
     "dsp_gpu_iir",
+    "dsp_gpu_iir_f64",
     "dsp_gpu_iir_multi",
+    "dsp_gpu_iir_multi_ex",
     "dsp_gpu_iir_settle",
     "dsp_gpu_biquad_swept",
     "dsp_gpu_device_count",
@@ -86,9 +91,17 @@ def lib() -> C.CDLL:
         L.dsp_gpu_convolve_stream.argtypes = [vp, vp, sz, sz, vp, i, vp, C.c_ulonglong, i, i, vp]
         L.dsp_gpu_convolve_stream.restype = i
         L.dsp_gpu_moving_average.argtypes = [vp, vp, sz, sz, i, i, vp]
+        L.dsp_gpu_moving_average_f64.argtypes = [vp, vp, sz, sz, i, i, vp]
+        L.dsp_gpu_moving_average_f64.restype = i
+        L.dsp_gpu_convolve_f64.argtypes = [vp, vp, sz, sz, vp, i, i, i, vp]
+        L.dsp_gpu_convolve_f64.restype = i
         L.dsp_gpu_iir.argtypes = [vp, vp, sz, sz, vp, vp, i, C.c_double, C.c_double, vp, i, i, vp]
         L.dsp_gpu_iir_multi.argtypes = [vp, vp, sz, sz, vp, vp, i, vp, vp, vp, i, vp]
         L.dsp_gpu_iir_multi.restype = i
+        L.dsp_gpu_iir_f64.argtypes = [vp, vp, sz, sz, vp, vp, i, C.c_double, C.c_double, vp, i, i, vp]
+        L.dsp_gpu_iir_f64.restype = i
+        L.dsp_gpu_iir_multi_ex.argtypes = [vp, vp, i, sz, sz, vp, vp, i, vp, vp, vp, i, i, vp]
+        L.dsp_gpu_iir_multi_ex.restype = i
         L.dsp_gpu_biquad_swept.argtypes = [vp, vp, vp, sz, sz, sz, i, C.c_double, vp, i, vp]
         L.dsp_gpu_biquad_swept.restype = i
         L.dsp_gpu_fft_columns.argtypes = [vp, vp, i, sz, i, vp]

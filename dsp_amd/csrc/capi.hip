@@ -497,76 +497,153 @@ int dsp_gpu_convolve_stream(const float *x, float *y, size_t channels, size_t n,
                          stream);
 }
 
-int dsp_gpu_moving_average(const float *x, float *y, size_t channels, size_t n, int npoints, int mem, void *stream) {
-    if (!x || !y) return fail(DSP_GPU_EINVAL, "dsp_gpu_moving_average: null buffer");
-    if (npoints < 1) return fail(DSP_GPU_EINVAL, "dsp_gpu_moving_average: npoints %d < 1", npoints);
-    if (bad_mem(mem)) return fail(DSP_GPU_EINVAL, "dsp_gpu_moving_average: mem %d", mem);
+}  // extern "C"
+
+namespace {
+template <typename T>
+int moving_average_impl(const char *who, const T *x, T *y, size_t channels, size_t n, int npoints, int mem, void *stream) {
+    if (!x || !y) return fail(DSP_GPU_EINVAL, "%s: null buffer", who);
+    if (npoints < 1) return fail(DSP_GPU_EINVAL, "%s: npoints %d < 1", who, npoints);
+    if (bad_mem(mem)) return fail(DSP_GPU_EINVAL, "%s: mem %d", who, mem);
     if (channels == 0 || n == 0) return DSP_GPU_OK;
     if (n < static_cast<size_t>(npoints))
-        return fail(DSP_GPU_EINVAL, "dsp_gpu_moving_average: n %zu < npoints %d (the reference reads out of bounds)", n, npoints);
+        return fail(DSP_GPU_EINVAL, "%s: n %zu < npoints %d (the reference reads out of bounds)", who, n, npoints);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const size_t bytes = channels * n * sizeof(float);
-    if (device_overlap(x, y, bytes, mem))
-        return fail(DSP_GPU_EINVAL, "dsp_gpu_moving_average: x and y overlap (not in-place on device buffers)");
-    if (mem == DSP_GPU_MEM_DEVICE) return launch_moving_average(x, y, channels, n, npoints, s);
-    const size_t row = n * sizeof(float);
+    const size_t bytes = channels * n * sizeof(T);
+    if (device_overlap(x, y, bytes, mem)) return fail(DSP_GPU_EINVAL, "%s: x and y overlap (not in-place on device buffers)", who);
+    auto run = [=](const T *dx, T *dy, size_t count) {
+        if constexpr (sizeof(T) == 8) return launch_moving_average_f64(dx, dy, count, n, npoints, s);
+        else return launch_moving_average(dx, dy, count, n, npoints, s);
+    };
+    if (mem == DSP_GPU_MEM_DEVICE) return run(x, y, channels);
+    const size_t row = n * sizeof(T);
     return host_route(x, row, bytes, y, row, channels, s, [=](const void *din, void *dout, size_t, size_t count, void *) {
-        return launch_moving_average(static_cast<const float *>(din), static_cast<float *>(dout), count, n, npoints, s);
+        return run(static_cast<const T *>(din), static_cast<T *>(dout), count);
+    });
+}
+}  // namespace
+
+extern "C" {
+
+int dsp_gpu_moving_average(const float *x, float *y, size_t channels, size_t n, int npoints, int mem, void *stream) {
+    return moving_average_impl<float>("dsp_gpu_moving_average", x, y, channels, n, npoints, mem, stream);
+}
+
+int dsp_gpu_moving_average_f64(const double *x, double *y, size_t channels, size_t n, int npoints, int mem, void *stream) {
+    return moving_average_impl<double>("dsp_gpu_moving_average_f64", x, y, channels, n, npoints, mem, stream);
+}
+
+// SincFilter<>::apply(SampleBuffer<double>&), filter.h:123-140: double samples, double taps (what the reference keeps:
+// filter.h:57), double arithmetic on the double matrix cores.  The tap cache holds the bytes of the double taps.
+int dsp_gpu_convolve_f64(const double *x, double *y, size_t channels, size_t n, const double *taps, int ntaps, int mode, int mem,
+                         void *stream) {
+    const char *who = "dsp_gpu_convolve_f64";
+    if (!x || !y || !taps) return fail(DSP_GPU_EINVAL, "%s: null buffer", who);
+    if (mode != DSP_GPU_CONV_AUTO && mode != DSP_GPU_CONV_DIRECT && mode != DSP_GPU_CONV_OVERLAP_SAVE)
+        return fail(DSP_GPU_EINVAL, "%s: mode %d", who, mode);
+    if (mode == DSP_GPU_CONV_OVERLAP_SAVE)
+        return fail(DSP_GPU_EUNSUPPORTED, "%s: double samples are filtered in the time domain (DIRECT; AUTO picks it)", who);
+    if (ntaps < 1 || ntaps > 4096) return fail(DSP_GPU_EINVAL, "%s: ntaps %d outside [1,4096]", who, ntaps);
+    if (bad_mem(mem)) return fail(DSP_GPU_EINVAL, "%s: mem %d", who, mem);
+    if (channels == 0 || n == 0) return DSP_GPU_OK;
+    const size_t bytes = channels * n * sizeof(double);
+    if (device_overlap(x, y, bytes, mem)) return fail(DSP_GPU_EINVAL, "%s: x and y overlap (the filter is not in-place on device buffers)", who);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    auto run = [=](const double *dx, double *dy, size_t count) -> int {
+        LeaseGuard te{TapLease{}, s};
+        if (int rc = acquire_taps(reinterpret_cast<const float *>(taps), 2 * ntaps, 0, s, &te.lease)) return rc;
+        return launch_fir_direct_f64(dx, dy, count, n, reinterpret_cast<const double *>(te.lease.d_taps), ntaps, s);
+    };
+    if (mem == DSP_GPU_MEM_DEVICE) return run(x, y, channels);
+    const size_t row = n * sizeof(double);
+    return host_route(x, row, bytes, y, row, channels, s, [=](const void *din, void *dout, size_t, size_t count, void *) {
+        return run(static_cast<const double *>(din), static_cast<double *>(dout), count);
     });
 }
 
-int dsp_gpu_iir(const float *x, float *y, size_t channels, size_t n, const double *a, const double *b, int poles,
-                double c0, double d0, double *state, int mode, int mem, void *stream) {
-    if (!x || !y || !a || !b) return fail(DSP_GPU_EINVAL, "dsp_gpu_iir: null buffer");
-    if (poles < 1 || poles > 20) return fail(DSP_GPU_EINVAL, "dsp_gpu_iir: poles %d outside [1,20]", poles);
-    if (mode != DSP_GPU_IIR_AUTO && mode != DSP_GPU_IIR_BATCH && mode != DSP_GPU_IIR_SCAN)
-        return fail(DSP_GPU_EINVAL, "dsp_gpu_iir: mode %d", mode);
-    if (bad_mem(mem)) return fail(DSP_GPU_EINVAL, "dsp_gpu_iir: mem %d", mem);
+}  // extern "C"
+
+namespace {
+
+// dsp_gpu_iir / dsp_gpu_iir_f64: T = float or double samples
+template <typename T>
+int iir_impl(const char *who, const T *x, T *y, size_t channels, size_t n, const double *a, const double *b, int poles,
+             double c0, double d0, double *state, int mode, int mem, void *stream) {
+    constexpr bool kF64 = sizeof(T) == 8;
+    if (!x || !y || !a || !b) return fail(DSP_GPU_EINVAL, "%s: null buffer", who);
+    if (poles < 1 || poles > 20) return fail(DSP_GPU_EINVAL, "%s: poles %d outside [1,20]", who, poles);
+    if (mode != DSP_GPU_IIR_AUTO && mode != DSP_GPU_IIR_BATCH && mode != DSP_GPU_IIR_SCAN && mode != DSP_GPU_IIR_BATCH_REF)
+        return fail(DSP_GPU_EINVAL, "%s: mode %d", who, mode);
+    if (bad_mem(mem)) return fail(DSP_GPU_EINVAL, "%s: mem %d", who, mem);
     if (channels == 0 || n == 0) return DSP_GPU_OK;
     IirCoef co{};
     co.poles = poles;
     for (int i = 0; i <= poles; ++i) {
         co.a[i] = a[i];
         co.b[i] = i == 0 ? 0.0 : b[i];  // coefficients.h:93 requires b[0] == 0
-        if (!std::isfinite(co.a[i]) || !std::isfinite(co.b[i])) return fail(DSP_GPU_EINVAL, "dsp_gpu_iir: non-finite coefficient");
+        if (!std::isfinite(co.a[i]) || !std::isfinite(co.b[i])) return fail(DSP_GPU_EINVAL, "%s: non-finite coefficient", who);
     }
     co.c0 = c0;
     co.d0 = d0;
-    if (!std::isfinite(c0) || !std::isfinite(d0)) return fail(DSP_GPU_EINVAL, "dsp_gpu_iir: non-finite c0/d0");
+    if (!std::isfinite(c0) || !std::isfinite(d0)) return fail(DSP_GPU_EINVAL, "%s: non-finite c0/d0", who);
     const bool auto_mode = mode == DSP_GPU_IIR_AUTO;
     if (auto_mode)  // one lane per channel needs tens of thousands of channels to fill the chip; measured crossover on
                     // 2^28 samples in total (scripts/iir_auto_threshold.py): 16,384 ch scan 0.53 / batch 1.08 ms,
-                    // 32,768 ch 0.67 / 0.58 ms
+                    // 32,768 ch 0.67 / 0.58 ms.  AUTO never picks the reference arithmetic.
         mode = (channels < 24576 && n >= 2048 && poles <= 8) ? DSP_GPU_IIR_SCAN : DSP_GPU_IIR_BATCH;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const size_t bytes = channels * n * sizeof(float);
+    const size_t bytes = channels * n * sizeof(T);
     if (device_overlap(x, y, bytes, mem)) {
         // the sequential kernel reads every tile before it writes it, so y == x is fine there; the scan's warm-up
         // samples are not (AUTO then takes the sequential kernel)
         if (x != y || (mode == DSP_GPU_IIR_SCAN && !auto_mode))
-            return fail(DSP_GPU_EINVAL, "dsp_gpu_iir: x and y overlap (only y == x in BATCH mode is in-place)");
-        mode = DSP_GPU_IIR_BATCH;
+            return fail(DSP_GPU_EINVAL, "%s: x and y overlap (only y == x in BATCH mode is in-place)", who);
+        if (mode == DSP_GPU_IIR_SCAN) mode = DSP_GPU_IIR_BATCH;
     }
     const size_t state_bytes = channels * 2 * static_cast<size_t>(poles) * sizeof(double);
-    auto run = [=](const float *dx, float *dy, size_t count, double *dstate) {
-        int rc = mode == DSP_GPU_IIR_SCAN ? launch_iir_scan(dx, dy, count, n, co, dstate, s)
-                                          : launch_iir_batch(dx, dy, count, n, co, dstate, nullptr, s);
-        if (rc == DSP_GPU_EUNSUPPORTED && auto_mode && mode == DSP_GPU_IIR_SCAN)  // ill-conditioned for the scan
-            rc = launch_iir_batch(dx, dy, count, n, co, dstate, nullptr, s);
-        return rc;
+    auto run = [=](const T *dx, T *dy, size_t count, double *dstate) {
+        if constexpr (kF64) {
+            if (mode == DSP_GPU_IIR_BATCH_REF) return launch_iir_batch_ref_f64(dx, dy, count, n, co, dstate, nullptr, s);
+            int rc = mode == DSP_GPU_IIR_SCAN ? launch_iir_scan_f64(dx, dy, count, n, co, dstate, s)
+                                              : launch_iir_batch_f64(dx, dy, count, n, co, dstate, nullptr, s);
+            if (rc == DSP_GPU_EUNSUPPORTED && auto_mode && mode == DSP_GPU_IIR_SCAN)
+                rc = launch_iir_batch_f64(dx, dy, count, n, co, dstate, nullptr, s);
+            return rc;
+        } else {
+            if (mode == DSP_GPU_IIR_BATCH_REF) return launch_iir_batch_ref(dx, dy, count, n, co, dstate, nullptr, s);
+            int rc = mode == DSP_GPU_IIR_SCAN ? launch_iir_scan(dx, dy, count, n, co, dstate, s)
+                                              : launch_iir_batch(dx, dy, count, n, co, dstate, nullptr, s);
+            if (rc == DSP_GPU_EUNSUPPORTED && auto_mode && mode == DSP_GPU_IIR_SCAN)  // ill-conditioned for the scan
+                rc = launch_iir_batch(dx, dy, count, n, co, dstate, nullptr, s);
+            return rc;
+        }
     };
     if (mem == DSP_GPU_MEM_DEVICE) return run(x, y, channels, state);
     // host route: channels are independent (the mode was chosen above for the whole batch, so every chunk runs the same
     // kernels); the small state array rides along whole
-    const size_t row = n * sizeof(float);
+    const size_t row = n * sizeof(T);
     return host_route(
         x, row, bytes, y, row, channels, s,
         [=](const void *din, void *dout, size_t u0, size_t count, void *daux) {
             double *dstate = static_cast<double *>(daux);
-            return run(static_cast<const float *>(din), static_cast<float *>(dout), count,
+            return run(static_cast<const T *>(din), static_cast<T *>(dout), count,
                        dstate ? dstate + u0 * 2 * static_cast<size_t>(poles) : nullptr);
         },
         state, state_bytes);
+}
+
+}  // namespace
+
+extern "C" {
+
+int dsp_gpu_iir(const float *x, float *y, size_t channels, size_t n, const double *a, const double *b, int poles,
+                double c0, double d0, double *state, int mode, int mem, void *stream) {
+    return iir_impl<float>("dsp_gpu_iir", x, y, channels, n, a, b, poles, c0, d0, state, mode, mem, stream);
+}
+
+int dsp_gpu_iir_f64(const double *x, double *y, size_t channels, size_t n, const double *a, const double *b, int poles,
+                    double c0, double d0, double *state, int mode, int mem, void *stream) {
+    return iir_impl<double>("dsp_gpu_iir_f64", x, y, channels, n, a, b, poles, c0, d0, state, mode, mem, stream);
 }
 
 int dsp_gpu_iir_settle(const double *a, const double *b, int poles, size_t *samples) {
@@ -584,29 +661,33 @@ int dsp_gpu_iir_settle(const double *a, const double *b, int poles, size_t *samp
     return iir_settle_samples(co, samples);
 }
 
-int dsp_gpu_iir_multi(const float *x, float *y, size_t channels, size_t n, const double *a, const double *b, int poles,
-                      const double *c0, const double *d0, double *state, int mem, void *stream) {
-    if (!x || !y || !a || !b) return fail(DSP_GPU_EINVAL, "dsp_gpu_iir_multi: null buffer");
+int dsp_gpu_iir_multi_ex(const void *xv, void *yv, int sample_type, size_t channels, size_t n, const double *a, const double *b,
+                         int poles, const double *c0, const double *d0, double *state, int mode, int mem, void *stream) {
+    if (!xv || !yv || !a || !b) return fail(DSP_GPU_EINVAL, "dsp_gpu_iir_multi: null buffer");
     if (poles < 1 || poles > 8) return fail(DSP_GPU_EINVAL, "dsp_gpu_iir_multi: poles %d outside [1,8]", poles);
+    if (sample_type != DSP_GPU_F32 && sample_type != DSP_GPU_F64) return fail(DSP_GPU_EINVAL, "dsp_gpu_iir_multi: sample type %d", sample_type);
+    if (mode != DSP_GPU_IIR_AUTO && mode != DSP_GPU_IIR_BATCH && mode != DSP_GPU_IIR_BATCH_REF)
+        return fail(DSP_GPU_EINVAL, "dsp_gpu_iir_multi: mode %d (one lane per channel: AUTO, BATCH or BATCH_REF)", mode);
     if (bad_mem(mem)) return fail(DSP_GPU_EINVAL, "dsp_gpu_iir_multi: mem %d", mem);
     if (channels == 0 || n == 0) return DSP_GPU_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
     IirCoef co{};
     co.poles = poles;
-    const size_t bytes = channels * n * sizeof(float);
+    const bool f64 = sample_type == DSP_GPU_F64, ref = mode == DSP_GPU_IIR_BATCH_REF;
+    const size_t bytes = channels * n * (f64 ? sizeof(double) : sizeof(float));
     const size_t state_bytes = channels * 2 * static_cast<size_t>(poles) * sizeof(double);
     const size_t ab = channels * static_cast<size_t>(poles + 1);  // doubles in a (and in b)
-    const float *dx = x;
-    float *dy = y;
+    const void *dx = xv;
+    void *dy = yv;
     double *dstate = state;
     IirPerChannel pc{a, b, c0, d0};
     HostStage hs;
     if (mem == DSP_GPU_MEM_HOST) {
         for (size_t i = 0; i < ab; ++i)
             if (!std::isfinite(a[i]) || !std::isfinite(b[i])) return fail(DSP_GPU_EINVAL, "dsp_gpu_iir_multi: non-finite coefficient");
-        if (int rc = stage_in(x, bytes, bytes, s, &hs)) return rc;
-        dx = static_cast<const float *>(hs.d_in);
-        dy = static_cast<float *>(hs.d_out);
+        if (int rc = stage_in(xv, bytes, bytes, s, &hs)) return rc;
+        dx = hs.d_in;
+        dy = hs.d_out;
         void *p = nullptr;
         if (int rc = workspace(WS_SCRATCH_A, (2 * ab + 2 * channels) * sizeof(double), &p)) return rc;
         double *dc = static_cast<double *>(p);
@@ -628,12 +709,29 @@ int dsp_gpu_iir_multi(const float *x, float *y, size_t channels, size_t n, const
             DSPGPU_HIP(hipMemcpyAsync(dstate, state, state_bytes, hipMemcpyHostToDevice, s));
         }
     }
-    if (int rc = launch_iir_batch(dx, dy, channels, n, co, dstate, &pc, s)) return rc;
+    int rc;
+    if (f64) {
+        const double *x64 = static_cast<const double *>(dx);
+        double *y64 = static_cast<double *>(dy);
+        rc = ref ? launch_iir_batch_ref_f64(x64, y64, channels, n, co, dstate, &pc, s)
+                 : launch_iir_batch_f64(x64, y64, channels, n, co, dstate, &pc, s);
+    } else {
+        const float *x32 = static_cast<const float *>(dx);
+        float *y32 = static_cast<float *>(dy);
+        rc = ref ? launch_iir_batch_ref(x32, y32, channels, n, co, dstate, &pc, s)
+                 : launch_iir_batch(x32, y32, channels, n, co, dstate, &pc, s);
+    }
+    if (rc) return rc;
     if (mem == DSP_GPU_MEM_HOST) {
         if (state) DSPGPU_HIP(hipMemcpyAsync(state, dstate, state_bytes, hipMemcpyDeviceToHost, s));
-        return stage_out(y, bytes, s, hs);
+        return stage_out(yv, bytes, s, hs);
     }
     return DSP_GPU_OK;
+}
+
+int dsp_gpu_iir_multi(const float *x, float *y, size_t channels, size_t n, const double *a, const double *b, int poles,
+                      const double *c0, const double *d0, double *state, int mem, void *stream) {
+    return dsp_gpu_iir_multi_ex(x, y, DSP_GPU_F32, channels, n, a, b, poles, c0, d0, state, DSP_GPU_IIR_BATCH, mem, stream);
 }
 
 int dsp_gpu_biquad_swept(const float *x, const float *fc, float *y, size_t channels, size_t n, size_t fc_stride, int kind,

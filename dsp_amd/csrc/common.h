@@ -49,6 +49,27 @@ __device__ __forceinline__ void store_stream_f4(float *p, float a, float b, floa
     dsp_f32x4 v = {a, b, c, d};
     __builtin_nontemporal_store(v, reinterpret_cast<dsp_f32x4 *>(p));
 }
+// 16-byte groups of samples of either type (SampleType float or double, sample_buffer.h:20)
+template <typename T>
+struct Smp;
+template <>
+struct Smp<float> {
+    typedef float vec __attribute__((ext_vector_type(4)));
+    static constexpr int kVec = 4;
+};
+template <>
+struct Smp<double> {
+    typedef double vec __attribute__((ext_vector_type(2)));
+    static constexpr int kVec = 2;
+};
+template <typename T>
+__device__ __forceinline__ typename Smp<T>::vec load_stream(const T *p) {  // use-once access, 16 bytes per lane (p 16-byte aligned)
+    return __builtin_nontemporal_load(reinterpret_cast<const typename Smp<T>::vec *>(p));
+}
+template <typename T>
+__device__ __forceinline__ void store_stream(T *p, typename Smp<T>::vec v) {
+    __builtin_nontemporal_store(v, reinterpret_cast<typename Smp<T>::vec *>(p));
+}
 // workgroup -> tile map giving each XCD one contiguous eighth of the tiles (see fft_device.h)
 __device__ __forceinline__ size_t xcd_tile_of(unsigned block, size_t chunk) {
     return static_cast<size_t>(block & 7u) * chunk + (block >> 3);
@@ -128,6 +149,9 @@ int launch_fir_os_segment(const float *x, float *y, size_t channels, size_t n, c
                           size_t seg0, int accumulate, int log2n, hipStream_t s);
 int launch_fir_spectrum(const float *d_taps, int ntaps, float2 *d_hspec, int log2n, hipStream_t s);
 int launch_moving_average(const float *x, float *y, size_t channels, size_t n, int npoints, hipStream_t s);
+int launch_moving_average_f64(const double *x, double *y, size_t channels, size_t n, int npoints, hipStream_t s);
+// direct FIR on double samples with double taps (fir_f64_kernels.hip, v_mfma_f64_16x16x4_f64); ntaps <= 4096
+int launch_fir_direct_f64(const double *x, double *y, size_t channels, size_t n, const double *d_taps, int ntaps, hipStream_t s);
 
 struct IirCoef {  // a Coefficients<Poles> without its history (coefficients.h:7-15), double as in the reference
     double a[21];  // up to Coefficients<20> (recursive_filters.h:30-31 designs 2..20 poles)
@@ -142,6 +166,15 @@ struct IirPerChannel {
 // per_channel == nullptr: `co` for every channel; otherwise only co.poles is read from `co` (poles <= 8).
 int launch_iir_batch(const float *x, float *y, size_t channels, size_t n, const IirCoef &co, double *state,
                      const IirPerChannel *per_channel, hipStream_t s);
+// The same kernel on double samples (iir_batch_ext.hip), and in the reference's own arithmetic -- coefficients.h:106-130 /
+// 172-182 operation for operation, no fused multiply-adds, the generic section's accumulator in the sample type.
+int launch_iir_batch_f64(const double *x, double *y, size_t channels, size_t n, const IirCoef &co, double *state,
+                         const IirPerChannel *per_channel, hipStream_t s);
+int launch_iir_batch_ref(const float *x, float *y, size_t channels, size_t n, const IirCoef &co, double *state,
+                         const IirPerChannel *per_channel, hipStream_t s);
+int launch_iir_batch_ref_f64(const double *x, double *y, size_t channels, size_t n, const IirCoef &co, double *state,
+                             const IirPerChannel *per_channel, hipStream_t s);
+int launch_iir_scan_f64(const double *x, double *y, size_t channels, size_t n, const IirCoef &co, double *state, hipStream_t s);
 int iir_settle_samples(const IirCoef &co, size_t *samples);
 int launch_iir_scan(const float *x, float *y, size_t channels, size_t n, const IirCoef &co, double *state,
                     hipStream_t s);

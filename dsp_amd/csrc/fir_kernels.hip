@@ -705,7 +705,9 @@ DSP_DEV double shfl_up_f64(double v, int delta) {
     hi = __shfl_up(hi, delta, 64);
     return __hiloint2double(hi, lo);
 }
-DSP_DEV int ma_pad(int i) { return i + ((i >> 4) << 2); }  // 4 pad floats per 16: conflict-free ds_read_b128
+// 16 pad BYTES per 16 samples (4 floats / 2 doubles): conflict-free ds_read_b128 for consecutive lanes on consecutive chunks
+template <typename T>
+DSP_DEV int ma_pad(int i) { return i + ((i >> 4) * Smp<T>::kVec); }
 
 // The reference's running sum (filter.h:88-98) starts from x[0..P) and then adds x[i+mid], drops
 // x[i-mid-1] with mid = P/2.  Algebraically that is
@@ -713,21 +715,25 @@ DSP_DEV int ma_pad(int i) { return i + ((i >> 4) << 2); }  // 4 pad floats per 1
 // (for odd P the plain centred mean; for even P -- reachable through numPoints(), which does not
 // re-force odd, filter.h:72-74 -- a 2*mid+1 window minus the constant x[P]).  Reproduced as is.
 //
-// A workgroup stages tile + window samples (aligned down to 4 so the loads are 16 bytes per lane)
-// and turns them into a two-level exclusive prefix sum in LDS: a float prefix inside every chunk of
+// A workgroup stages tile + window samples (aligned down to a 16-byte group so the loads are 16 bytes per lane)
+// and turns them into a two-level exclusive prefix sum in LDS: a prefix in the sample type inside every chunk of
 // 16 samples (overwriting the samples) plus a DOUBLE prefix over the chunk sums (block scan with wave
 // shuffles).  y[j] = (G[j + window] - G[j]) / P with G[u] = chunk_prefix[u >> 4] + in_chunk[u];
 // consecutive lanes take consecutive outputs, so the LDS reads are conflict-free and the global
 // stores coalesced.  Nothing is carried along the signal, hence none of the reference's accumulated
-// float drift.  LDS: float xs[ma_pad(span)], double pc[chunks], double wave_tot[4].
-template <bool ALIGNED, int kMaPer>
-__global__ __launch_bounds__(kThreads) void moving_average_kernel(const float *__restrict__ x, float *__restrict__ y,
+// drift.  LDS: T xs[ma_pad(span)], double pc[chunks], double wave_tot[4].
+// T = float (BASELINE's type) or double (SampleBuffer<double>, what the reference's own callers filter:
+// eval/moving_average_filter_demo/main.cpp:14).
+template <bool ALIGNED, int kMaPer, typename T = float>
+__global__ __launch_bounds__(kThreads) void moving_average_kernel(const T *__restrict__ x, T *__restrict__ y,
                                                                   size_t n, int npoints, int span, int cpt) {
+    using V = typename Smp<T>::vec;
+    constexpr int kVec = Smp<T>::kVec;
     constexpr int kMaTile = kThreads * kMaPer;
-    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int chunks = span >> 4;  // span is a multiple of 16
-    float *xs = smem_f;
-    double *pc = reinterpret_cast<double *>(smem_f + ma_pad(span));
+    T *xs = reinterpret_cast<T *>(smem_raw);
+    double *pc = reinterpret_cast<double *>(xs + ma_pad<T>(span));  // ma_pad(span) * sizeof(T) is a multiple of 16
     double *wave_tot = pc + chunks;
     const int tid = threadIdx.x;
     const size_t ch = blockIdx.y;
@@ -740,75 +746,72 @@ __global__ __launch_bounds__(kThreads) void moving_average_kernel(const float *_
     const unsigned bx = (gridDim.x & 7u) == 0 ? (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
     const long long out0 = static_cast<long long>(bx) * kMaTile;  // first output of the tile
     const long long first = out0 - mid;                                   // first sample the tile needs
-    const long long seg0 = first & ~3ll;                                  // staged from here (16-byte aligned)
-    const int shift = static_cast<int>(first - seg0);                     // 0..3
-    const float *xc = x + ch * n;
-    float *yc = y + ch * n;
-    const float corr = ((npoints & 1) == 0 && npoints < nn) ? xc[npoints] : 0.0f;
+    const long long seg0 = first & ~static_cast<long long>(kVec - 1);     // staged from here (16-byte aligned)
+    const int shift = static_cast<int>(first - seg0);                     // 0..kVec-1
+    const T *xc = x + ch * n;
+    T *yc = y + ch * n;
+    const T corr = ((npoints & 1) == 0 && npoints < nn) ? xc[npoints] : T(0);
 
-    int u0 = tid * 4;
+    int u0 = tid * kVec;
     if (ALIGNED) {
         // four loads in flight per thread, no branch between them (a bounds branch around every load makes the compiler
-        // wait for each one before issuing the next).  n and seg0 are multiples of 4, so a float4 lies wholly inside
+        // wait for each one before issuing the next).  n and seg0 are multiples of the group, so a group lies wholly inside
         // the channel or wholly outside; outside ones are aimed at the channel's first sample and zeroed afterwards.
-        constexpr int kStep = kThreads * 4;
+        constexpr int kStep = kThreads * kVec;
         if (seg0 >= 0 && seg0 + span <= nn) {  // interior tile: nothing to clamp
             for (; u0 + 3 * kStep < span; u0 += 4 * kStep) {
-                float4 v[4];
+                V v[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = load_stream_f4(xc + seg0 + u0 + i * kStep);
+                for (int i = 0; i < 4; ++i) v[i] = load_stream<T>(xc + seg0 + u0 + i * kStep);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) *reinterpret_cast<float4 *>(xs + ma_pad(u0 + i * kStep)) = v[i];
+                for (int i = 0; i < 4; ++i) *reinterpret_cast<V *>(xs + ma_pad<T>(u0 + i * kStep)) = v[i];
             }
         }
         for (; u0 + 3 * kStep < span; u0 += 4 * kStep) {
-            float4 v[4];
+            V v[4];
             bool ok[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const long long g = seg0 + u0 + i * kStep;
                 ok[i] = g >= 0 && g < nn;
-                v[i] = load_stream_f4(xc + (ok[i] ? g : 0));
+                v[i] = load_stream<T>(xc + (ok[i] ? g : 0));
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                *reinterpret_cast<float4 *>(xs + ma_pad(u0 + i * kStep)) = ok[i] ? v[i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            for (int i = 0; i < 4; ++i) *reinterpret_cast<V *>(xs + ma_pad<T>(u0 + i * kStep)) = ok[i] ? v[i] : V(0);
         }
     }
-    for (int u = u0; u < span; u += kThreads * 4) {
+    for (int u = u0; u < span; u += kThreads * kVec) {
         const long long g = seg0 + u;
-        float4 v;
-        if (ALIGNED && g >= 0 && g + 3 < nn) {
-            v = load_stream_f4(xc + g);
+        V v;
+        if (ALIGNED && g >= 0 && g + kVec - 1 < nn) {
+            v = load_stream<T>(xc + g);
         } else {
-            v.x = (g >= 0 && g < nn) ? xc[g] : 0.0f;
-            v.y = (g + 1 >= 0 && g + 1 < nn) ? xc[g + 1] : 0.0f;
-            v.z = (g + 2 >= 0 && g + 2 < nn) ? xc[g + 2] : 0.0f;
-            v.w = (g + 3 >= 0 && g + 3 < nn) ? xc[g + 3] : 0.0f;
+#pragma unroll
+            for (int k = 0; k < kVec; ++k) v[k] = (g + k >= 0 && g + k < nn) ? xc[g + k] : T(0);
         }
-        *reinterpret_cast<float4 *>(xs + ma_pad(u)) = v;
+        *reinterpret_cast<V *>(xs + ma_pad<T>(u)) = v;
     }
     __syncthreads();
 
     // round k: thread t owns chunk t + 256*k (consecutive lanes on consecutive chunks: the 20-dword lane
-    // stride keeps the 16-byte LDS accesses conflict-free).  In-chunk exclusive prefixes (float, in place),
+    // stride keeps the 16-byte LDS accesses conflict-free).  In-chunk exclusive prefixes (sample type, in place),
     // then a block-wide exclusive scan of the chunk totals in double, rounds chained through `base`.
     const int lane = tid & 63, wave = tid >> 6;
     double base = 0.0;
     for (int k = 0; k < cpt; ++k) {
         const int c = tid + kThreads * k;
-        float run = 0.0f;
+        T run = T(0);
         if (c < chunks) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                float4 *p = reinterpret_cast<float4 *>(xs + ma_pad(16 * c + 4 * q));
-                const float4 v = *p;
-                float4 e;
-                e.x = run;
-                e.y = e.x + v.x;
-                e.z = e.y + v.y;
-                e.w = e.z + v.z;
-                run = e.w + v.w;
+            for (int q = 0; q < 16 / kVec; ++q) {
+                V *p = reinterpret_cast<V *>(xs + ma_pad<T>(16 * c + kVec * q));
+                const V v = *p;
+                V e;
+#pragma unroll
+                for (int i = 0; i < kVec; ++i) {
+                    e[i] = run;
+                    run = run + v[i];
+                }
                 *p = e;
             }
         }
@@ -831,15 +834,20 @@ __global__ __launch_bounds__(kThreads) void moving_average_kernel(const float *_
     const double inv = 1.0 / static_cast<double>(npoints);
     const double dcorr = static_cast<double>(corr);
     const long long hi = (nn - mid > mid + 1) ? nn - mid : mid + 1;  // out[mid] is always written (filter.h:93)
+    // double samples: divide as the reference does (sum / M, filter.h:93,97) rather than multiply by the reciprocal
+    auto mean = [&](double sum) -> T {
+        if constexpr (sizeof(T) == 8) return (sum - dcorr) / static_cast<double>(npoints);
+        else return static_cast<T>((sum - dcorr) * inv);
+    };
     if (out0 >= mid && out0 + kMaTile <= hi) {  // interior tile: every output has its full window
-        float *yt = yc + out0;
+        T *yt = yc + out0;
 #pragma unroll
         for (int i = 0; i < kMaPer; ++i) {
             const int jrel = kThreads * i + tid;
             const int lo = jrel + shift, up = lo + window;  // window = staged samples [lo, up)
             const double sum = (pc[up >> 4] - pc[lo >> 4]) +
-                               (static_cast<double>(xs[ma_pad(up)]) - static_cast<double>(xs[ma_pad(lo)]));
-            __builtin_nontemporal_store(static_cast<float>((sum - dcorr) * inv), yt + jrel);
+                               (static_cast<double>(xs[ma_pad<T>(up)]) - static_cast<double>(xs[ma_pad<T>(lo)]));
+            __builtin_nontemporal_store(mean(sum), yt + jrel);
         }
         return;
     }
@@ -848,12 +856,12 @@ __global__ __launch_bounds__(kThreads) void moving_average_kernel(const float *_
         const int jrel = kThreads * i + tid;
         const long long j = out0 + jrel;
         if (j >= nn) continue;
-        float v = 0.0f;
+        T v = T(0);
         if (j >= mid && j < hi) {
             const int lo = jrel + shift, up = lo + window;
             const double sum = (pc[up >> 4] - pc[lo >> 4]) +
-                               (static_cast<double>(xs[ma_pad(up)]) - static_cast<double>(xs[ma_pad(lo)]));
-            v = static_cast<float>((sum - dcorr) * inv);
+                               (static_cast<double>(xs[ma_pad<T>(up)]) - static_cast<double>(xs[ma_pad<T>(lo)]));
+            v = mean(sum);
         }
         __builtin_nontemporal_store(v, yc + j);
     }
@@ -1038,25 +1046,28 @@ int launch_fir_os_segment(const float *x, float *y, size_t channels, size_t n, c
                      OsExtra{n, seg0, accumulate, 1, 0}, log2n, s);
 }
 
-int launch_moving_average(const float *x, float *y, size_t channels, size_t n, int npoints, hipStream_t s) {
+namespace {
+template <typename T>
+int launch_moving_average_t(const T *x, T *y, size_t channels, size_t n, int npoints, hipStream_t s) {
     if (npoints > 8192) return fail(DSP_GPU_EUNSUPPORTED, "moving average: npoints %d > 8192", npoints);
     for (; channels > kMaxGridY; channels -= kMaxGridY, x += kMaxGridY * n, y += kMaxGridY * n)  // grid.y is 16 bits
-        if (int rc = launch_moving_average(x, y, kMaxGridY, n, npoints, s)) return rc;
+        if (int rc = launch_moving_average_t<T>(x, y, kMaxGridY, n, npoints, s)) return rc;
+    constexpr int kVec = Smp<T>::kVec;
     const int window = 2 * (npoints / 2) + 1;
     // outputs per thread: the full 16 unless the whole channel fits a smaller tile (many short channels would
     // otherwise stage and scan mostly padding)
     int per = kMaPerMax;
     while (per > 1 && static_cast<size_t>(kThreads) * (per / 2) >= n) per /= 2;
     const int tile = kThreads * per;
-    // staged samples: tile + window, + 3 for the aligned start, + 1 so index `up` of the last output exists
-    const int span = ((tile + window + 4 + 15) / 16) * 16;
+    // staged samples: tile + window, + kVec - 1 for the aligned start, + 1 so index `up` of the last output exists
+    const int span = ((tile + window + kVec + 15) / 16) * 16;
     const int chunks = span / 16;
     const int cpt = (chunks + kThreads - 1) / kThreads;
-    const size_t lds_bytes = static_cast<size_t>(span + (span / 16) * 4) * sizeof(float) + static_cast<size_t>(chunks + 4 * cpt) * sizeof(double);
+    const size_t lds_bytes = static_cast<size_t>(span + (span / 16) * kVec) * sizeof(T) + static_cast<size_t>(chunks + 4 * cpt) * sizeof(double);
     const size_t blocks = (n + tile - 1) / tile;
-    const bool aligned = (n % 4 == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0);
-    void (*kern)(const float *, float *, size_t, int, int, int) = nullptr;
-#define DSPGPU_MA_PICK(PER) kern = aligned ? moving_average_kernel<true, PER> : moving_average_kernel<false, PER>
+    const bool aligned = (n % kVec == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0);
+    void (*kern)(const T *, T *, size_t, int, int, int) = nullptr;
+#define DSPGPU_MA_PICK(PER) kern = aligned ? moving_average_kernel<true, PER, T> : moving_average_kernel<false, PER, T>
     switch (per) {
     case 1: DSPGPU_MA_PICK(1); break;
     case 2: DSPGPU_MA_PICK(2); break;
@@ -1069,6 +1080,14 @@ int launch_moving_average(const float *x, float *y, size_t channels, size_t n, i
         if (int rc = allow_full_lds(reinterpret_cast<const void *>(kern))) return rc;
     hipLaunchKernelGGL(kern, dim3(blocks, channels), dim3(kThreads), lds_bytes, s, x, y, n, npoints, span, cpt);
     return check_launch("moving_average_kernel");
+}
+}  // namespace
+
+int launch_moving_average(const float *x, float *y, size_t channels, size_t n, int npoints, hipStream_t s) {
+    return launch_moving_average_t<float>(x, y, channels, n, npoints, s);
+}
+int launch_moving_average_f64(const double *x, double *y, size_t channels, size_t n, int npoints, hipStream_t s) {
+    return launch_moving_average_t<double>(x, y, channels, n, npoints, s);
 }
 
 }  // namespace dspgpu

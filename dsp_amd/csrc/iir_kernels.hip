@@ -33,6 +33,7 @@
 #include <vector>
 
 #include "common.h"
+#include "iir_batch_core.h"
 
 namespace dspgpu {
 // Ablation switches for scripts/iir_scan_ablate.hip, which compiles this file with DSPGPU_SCAN_ABLATE defined and times the
@@ -46,209 +47,12 @@ __device__ int g_scan_ablate = 0;
 #endif
 namespace {
 
-#define DSP_DEV __device__ __forceinline__
+using namespace iirb;  // the recursion step, the row runners and the batch kernel: iir_batch_core.h
 
-constexpr int kWave = 64;
-
-// One recursion step.  xh[i] = x[t-1-i], vh[i] = v[t-1-i].  The feedback term through v[t-1] is
-// applied last so the loop-carried dependency is a single fma.
-// C: IirCoef (wave-uniform, read from the kernel arguments) or LaneCoef<P> (one set per lane, in registers).
-template <int P>
-struct LaneCoef {
-    double a[P + 1], b[P + 1], c0, d0;
-};
-
-template <int P, typename C>
-DSP_DEV double iir_step(double x0, double (&xh)[P], double (&vh)[P], const C &co) {
-    double f = co.a[0] * x0;
-#pragma unroll
-    for (int k = 0; k < P; ++k) f = fma(co.a[k + 1], xh[k], f);
-#pragma unroll
-    for (int k = P - 1; k >= 1; --k) f = fma(co.b[k + 1], vh[k], f);
-    const double v = fma(co.b[1], vh[0], f);
-#pragma unroll
-    for (int k = P - 1; k >= 1; --k) {
-        xh[k] = xh[k - 1];
-        vh[k] = vh[k - 1];
-    }
-    xh[0] = x0;
-    vh[0] = v;
-    return v;
-}
-
-// Run `LEN` samples of one LDS row (stride 1).  STORE: overwrite the row with y.
-template <int P, int LEN, bool STORE, typename C>
-DSP_DEV void run_row(float *row, double (&xh)[P], double (&vh)[P], const C &co) {
-#pragma unroll 16
-    for (int i = 0; i < LEN; ++i) {
-        const double x0 = static_cast<double>(row[i]);
-        const double v = iir_step<P>(x0, xh, vh, co);
-        if (STORE) row[i] = static_cast<float>(fma(v, co.c0, x0 * co.d0));
-    }
-}
-
-template <int P, bool STORE, typename C>
-DSP_DEV void run_row_partial(float *row, int count, double (&xh)[P], double (&vh)[P], const C &co) {
-#pragma unroll 1
-    for (int i = 0; i < count; ++i) {
-        const double x0 = static_cast<double>(row[i]);
-        const double v = iir_step<P>(x0, xh, vh, co);
-        if (STORE) row[i] = static_cast<float>(fma(v, co.c0, x0 * co.d0));
-    }
-}
-
-// The same over a 16-byte aligned row, four samples per LDS access.
+// the float rows of the scan below, in the fast (double, fused multiply-add) arithmetic
 template <int P, int LEN, bool STORE, typename C>
 DSP_DEV void run_row4(float *row, double (&xh)[P], double (&vh)[P], const C &co) {
-#pragma unroll
-    for (int i = 0; i < LEN; i += 4) {
-        float4 q = *reinterpret_cast<const float4 *>(row + i);
-        float *e = reinterpret_cast<float *>(&q);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const double x0 = static_cast<double>(e[k]);
-            const double v = iir_step<P>(x0, xh, vh, co);
-            if (STORE) e[k] = static_cast<float>(fma(v, co.c0, x0 * co.d0));
-        }
-        if (STORE) *reinterpret_cast<float4 *>(row + i) = q;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// batch: one lane per channel
-// ---------------------------------------------------------------------------------------------
-constexpr int kBt = 128;         // samples per tile row: 512-byte row segments (256-byte ones cap a plain copy at 4.4 TB/s, scripts/copy_patterns3.hip;
-                                 // 256-sample rows, two workgroups per CU by their own LDS: 0.745 against 0.77 of 8 TB/s)
-constexpr int kBtPad = kBt + 4;  // rows 16-byte aligned; lane stride 132 dwords: 16-byte row walks are conflict-free
-constexpr int kBtIters = kBt * kWave / (kWave * 4);  // float4 loads per lane per tile = 16
-
-template <bool ALIGNED>
-DSP_DEV void batch_load(const float *__restrict__ x, size_t channels, size_t n, size_t ch0, size_t t0, int lane,
-                        float4 (&pre)[kBtIters]) {
-    constexpr int kLanesPerRow = kBt / 4;            // 16 lanes cover one row
-    constexpr int kRowsPerIter = kWave / kLanesPerRow;  // 4 rows per wave instruction
-    if (ALIGNED && ch0 + kWave <= channels && t0 + kBt <= n) {  // a full tile: no bounds tests between the loads
-        const float *p = x + (ch0 + lane / kLanesPerRow) * n + t0 + (lane % kLanesPerRow) * 4;
-        const size_t step = kRowsPerIter * n;
-#pragma unroll
-        for (int it = 0; it < kBtIters; ++it) pre[it] = load_stream_f4(p + it * step);
-        return;
-    }
-#pragma unroll
-    for (int it = 0; it < kBtIters; ++it) {
-        const size_t ch = ch0 + it * kRowsPerIter + lane / kLanesPerRow;
-        const size_t g = t0 + (lane % kLanesPerRow) * 4;
-        float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (ch < channels) {
-            const float *p = x + ch * n + g;
-            if (ALIGNED && g + 3 < n) {
-                v = load_stream_f4(p);
-            } else {
-                if (g < n) v.x = p[0];
-                if (g + 1 < n) v.y = p[1];
-                if (g + 2 < n) v.z = p[2];
-                if (g + 3 < n) v.w = p[3];
-            }
-        }
-        pre[it] = v;
-    }
-}
-
-// P: compiled recursion order; sp <= P: the caller's order (its state is [ch][2*sp]; the top P - sp
-// coefficients are zero, which leaves every sum unchanged).  PERCH: one coefficient set per channel.
-template <int P, bool ALIGNED, bool PERCH>
-__global__ __launch_bounds__(kWave) void iir_batch_kernel(const float *__restrict__ x, float *__restrict__ y,
-                                                           size_t channels, size_t n, IirCoef uco,
-                                                           double *__restrict__ state, size_t groups, size_t chunk,
-                                                           int sp, IirPerChannel pc) {
-    __shared__ __attribute__((aligned(16))) float tile[kWave * kBtPad];
-    constexpr int kLanesPerRow = kBt / 4;
-    constexpr int kRowsPerIter = kWave / kLanesPerRow;
-    const int lane = threadIdx.x;
-    const size_t group = xcd_tile_of(blockIdx.x, chunk);  // each XCD owns a contiguous range of channels
-    if (group >= groups) return;
-    const size_t ch0 = group * kWave;
-    const size_t ch = ch0 + lane;
-    const bool live = ch < channels;
-
-    double xh[P], vh[P];
-#pragma unroll
-    for (int i = 0; i < P; ++i) {
-        xh[i] = (live && state && i < sp) ? state[ch * 2 * sp + i] : 0.0;
-        vh[i] = (live && state && i < sp) ? state[ch * 2 * sp + sp + i] : 0.0;
-    }
-    typename std::conditional<PERCH, LaneCoef<P>, IirCoef>::type co;
-    if constexpr (PERCH) {
-#pragma unroll
-        for (int i = 0; i <= P; ++i) {
-            co.a[i] = (live && i <= sp) ? pc.a[ch * (sp + 1) + i] : 0.0;
-            co.b[i] = (live && i <= sp && i > 0) ? pc.b[ch * (sp + 1) + i] : 0.0;
-        }
-        co.c0 = pc.c0 ? (live ? pc.c0[ch] : 0.0) : 1.0;  // Coefficients' defaults (coefficients.h:11-12)
-        co.d0 = pc.d0 ? (live ? pc.d0[ch] : 0.0) : 0.0;
-    } else {
-        co = uco;
-    }
-
-    const size_t ntiles = (n + kBt - 1) / kBt;
-    float4 pre[kBtIters];
-    batch_load<ALIGNED>(x, channels, n, ch0, 0, lane, pre);
-    for (size_t tl = 0; tl < ntiles; ++tl) {
-        const size_t t0 = tl * kBt;
-#pragma unroll
-        for (int it = 0; it < kBtIters; ++it) {
-            *reinterpret_cast<float4 *>(tile + (it * kRowsPerIter + lane / kLanesPerRow) * kBtPad + (lane % kLanesPerRow) * 4) = pre[it];
-        }
-        __syncthreads();
-        if (tl + 1 < ntiles) batch_load<ALIGNED>(x, channels, n, ch0, t0 + kBt, lane, pre);
-        if (live) {
-            float *row = tile + lane * kBtPad;
-            if (t0 + kBt <= n) run_row4<P, kBt, true>(row, xh, vh, co);
-            else run_row_partial<P, true>(row, static_cast<int>(n - t0), xh, vh, co);
-        }
-        __syncthreads();
-        if (ALIGNED && ch0 + kWave <= channels && t0 + kBt <= n) {  // full tile: LDS reads four at a time, no bounds tests
-            const float *src = tile + (lane / kLanesPerRow) * kBtPad + (lane % kLanesPerRow) * 4;
-            float *p = y + (ch0 + lane / kLanesPerRow) * n + t0 + (lane % kLanesPerRow) * 4;
-#pragma unroll
-            for (int it0 = 0; it0 < kBtIters; it0 += 4) {
-                float4 q[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) q[i] = *reinterpret_cast<const float4 *>(src + (it0 + i) * kRowsPerIter * kBtPad);
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    store_stream_f4(p + static_cast<size_t>((it0 + i) * kRowsPerIter) * n, q[i].x, q[i].y, q[i].z, q[i].w);
-            }
-            __syncthreads();
-            continue;
-        }
-#pragma unroll
-        for (int it = 0; it < kBtIters; ++it) {
-            const size_t c = ch0 + it * kRowsPerIter + lane / kLanesPerRow;
-            const size_t g = t0 + (lane % kLanesPerRow) * 4;
-            if (c >= channels || g >= n) continue;
-            const float *src = tile + (it * kRowsPerIter + lane / kLanesPerRow) * kBtPad + (lane % kLanesPerRow) * 4;
-            float *p = y + c * n + g;
-            if (ALIGNED && g + 3 < n) {
-                const float4 q = *reinterpret_cast<const float4 *>(src);
-                store_stream_f4(p, q.x, q.y, q.z, q.w);
-            } else {
-                p[0] = src[0];
-                if (g + 1 < n) p[1] = src[1];
-                if (g + 2 < n) p[2] = src[2];
-                if (g + 3 < n) p[3] = src[3];
-            }
-        }
-        __syncthreads();
-    }
-    if (live && state) {
-#pragma unroll
-        for (int i = 0; i < P; ++i) {
-            if (i >= sp) break;
-            state[ch * 2 * sp + i] = xh[i];
-            state[ch * 2 * sp + sp + i] = vh[i];
-        }
-    }
+    run_rowv<P, LEN, STORE, IIR_ARITH_FMA>(row, xh, vh, co);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1049,40 +853,6 @@ int scan_dispatch(const float *x, float *y, size_t channels, size_t n, const Iir
                       : scan_launch<P, ALIGNED, false>(x, y, channels, n, co, state_in, state, *plan, s);
 }
 
-template <int P, bool ALIGNED>
-int batch_dispatch(const float *x, float *y, size_t channels, size_t n, const IirCoef &co, double *state,
-                   const IirPerChannel *pc, hipStream_t s) {
-    const size_t groups = (channels + kWave - 1) / kWave;
-    const size_t chunk = (groups + 7) / 8;
-    if (8 * chunk > 0x7fffffffull) return fail(DSP_GPU_EUNSUPPORTED, "IIR batch: too many channels");
-    const dim3 grid(static_cast<unsigned>(8 * chunk));
-    // Dynamic LDS nobody uses: it only lowers the number of workgroups a CU holds.  Up to four poles the recursion is
-    // cheap enough for TWO one-wave workgroups per CU to keep up with memory, and with 2 x 32 KB instead of 4 x 32 KB of
-    // tiles in flight per CU the memory system runs faster (the round's in-flight lesson):
-    // 262,144 x 4,096, 4 poles: 1.485 -> 1.375 ms (0.72 -> 0.78 of 8 TB/s); 3 per CU 0.70, 1 per CU 0.45.  From six
-    // poles on the arithmetic needs all four SIMDs (6 poles: 1.49 ms at four per CU, 1.68 at two).
-    // DSP_GPU_IIR_BATCH_LDS_PAD=<bytes> overrides (0 = four per CU).
-    static const int pad_env = [] {
-        const char *e = std::getenv("DSP_GPU_IIR_BATCH_LDS_PAD");
-        return e ? std::atoi(e) : -1;
-    }();
-    const unsigned pad = pad_env >= 0 ? static_cast<unsigned>(pad_env) : (P <= 4 ? 30000u : 0u);
-    if constexpr (P <= 8) {
-        if (pc) {
-            hipLaunchKernelGGL((iir_batch_kernel<P, ALIGNED, true>), grid, dim3(kWave), pad, s, x, y, channels, n, co, state,
-                               groups, chunk, co.poles, *pc);
-            return check_launch("iir_batch_kernel<per-channel>");
-        }
-    }
-    hipLaunchKernelGGL((iir_batch_kernel<P, ALIGNED, false>), grid, dim3(kWave), pad, s, x, y, channels, n, co, state, groups,
-                       chunk, co.poles, IirPerChannel{});
-    return check_launch("iir_batch_kernel");
-}
-
-bool is_aligned(const float *x, const float *y, size_t n) {
-    return n % 4 == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0 && reinterpret_cast<uintptr_t>(y) % 16 == 0;
-}
-
 }  // namespace
 
 // Samples after which the response to ANY initial state has decayed below 2^-44 of it (||A^k||_inf <= 2^-44 for the
@@ -1104,33 +874,9 @@ int iir_settle_samples(const IirCoef &co, size_t *samples) {
 bool iir_tables_in_use(int dev) { return tables_in_use(dev); }
 void release_iir_tables(int dev) { release_tables(dev); }
 
-int launch_iir_batch(const float *x, float *y, size_t channels, size_t n, const IirCoef &co, double *state,
-                     const IirPerChannel *pc, hipStream_t s) {
-    const bool al = is_aligned(x, y, n);
-    if (pc && co.poles > 8) return fail(DSP_GPU_EUNSUPPORTED, "per-channel IIR coefficients: poles %d > 8", co.poles);
-#define DSP_IIR_BATCH_CASE(P) \
-    return al ? batch_dispatch<P, true>(x, y, channels, n, co, state, pc, s) : batch_dispatch<P, false>(x, y, channels, n, co, state, pc, s)
-    switch (co.poles) {  // orders without a kernel of their own run on the next one up (zero top coefficients)
-    case 1: DSP_IIR_BATCH_CASE(1);
-    case 2: DSP_IIR_BATCH_CASE(2);
-    case 3: DSP_IIR_BATCH_CASE(3);
-    case 4: DSP_IIR_BATCH_CASE(4);
-    case 5: DSP_IIR_BATCH_CASE(5);
-    case 6: DSP_IIR_BATCH_CASE(6);
-    case 7: DSP_IIR_BATCH_CASE(7);
-    case 8: DSP_IIR_BATCH_CASE(8);
-    case 9: case 10: DSP_IIR_BATCH_CASE(10);
-    case 11: case 12: DSP_IIR_BATCH_CASE(12);
-    case 13: case 14: case 15: case 16: DSP_IIR_BATCH_CASE(16);
-    case 17: case 18: case 19: case 20: DSP_IIR_BATCH_CASE(20);
-    default: return fail(DSP_GPU_EINVAL, "poles %d outside [1,20]", co.poles);
-    }
-#undef DSP_IIR_BATCH_CASE
-}
-
 int launch_iir_scan(const float *x, float *y, size_t channels, size_t n, const IirCoef &co, double *state,
                     hipStream_t s) {
-    const bool al = is_aligned(x, y, n);
+    const bool al = iirb::is_aligned<float>(x, y, n);
 #define DSP_IIR_SCAN_CASE(P) \
     return al ? scan_dispatch<P, true>(x, y, channels, n, co, state, s) : scan_dispatch<P, false>(x, y, channels, n, co, state, s)
     switch (co.poles) {

@@ -156,6 +156,20 @@ def convolve(x, taps, mode: str = "auto", out=None):
     return y
 
 
+def convolve_f64(x, taps, mode: str = "auto", out=None):
+    """The same filter on double samples with double taps: SincFilter<>::apply(SampleBuffer<double>&), filter.h:123-140
+    (time domain on the double matrix cores; mode "auto" or "direct")."""
+    x, px, mem = _prep(x, np.float64, "float64")
+    taps = np.ascontiguousarray(taps, dtype=np.float64)
+    n = x.shape[-1]
+    channels = int(np.prod(x.shape[:-1])) if x.ndim > 1 else 1
+    y = _out(out, x, tuple(x.shape), np.float64, "float64")
+    with _on_device(x):
+        capi.check(capi.lib().dsp_gpu_convolve_f64(px, _ptr(y), channels, n, taps.ctypes.data, taps.size, _MODES[mode], mem,
+                                                   _stream_of(x)))
+    return y
+
+
 def convolve_stream(x, taps, history, position: int, mode: str = "direct", out=None):
     """One chunk of a streamed FIR.  history: [channels, len(taps)-1] fp32 where x lives, updated in place;
     position = samples of the stream consumed so far (0 starts it; the first len(taps)-1 outputs of the
@@ -190,15 +204,23 @@ def moving_average(x, npoints: int, out=None):
     return y
 
 
-_IIR_MODES = {"auto": capi.IIR_AUTO, "batch": capi.IIR_BATCH, "scan": capi.IIR_SCAN}
+def moving_average_f64(x, npoints: int, out=None):
+    """MovingAverageFilter::apply on double samples (filter.h:81-101)."""
+    x, px, mem = _prep(x, np.float64, "float64")
+    n = x.shape[-1]
+    channels = int(np.prod(x.shape[:-1])) if x.ndim > 1 else 1
+    y = _out(out, x, tuple(x.shape), np.float64, "float64")
+    with _on_device(x):
+        capi.check(capi.lib().dsp_gpu_moving_average_f64(px, _ptr(y), channels, n, int(npoints), mem, _stream_of(x)))
+    return y
 
 
-def iir(x, a, b, c0: float = 1.0, d0: float = 0.0, state=None, mode: str = "auto", out=None):
-    """IIR recursion with feedback ADDED (coefficients.h:106-130).
+_IIR_MODES = {"auto": capi.IIR_AUTO, "batch": capi.IIR_BATCH, "scan": capi.IIR_SCAN, "batch_ref": capi.IIR_BATCH_REF}
 
-    state: [channels, 2*poles] float64 {x[t-1..t-poles], v[t-1..t-poles]}, updated in place
-    (the reference's x[]/y[] history, coefficients.h:11-12)."""
-    x, px, mem = _prep(x, np.float32, "float32")
+
+def _iir_any(x, f64, a, b, c0, d0, state, mode, out):
+    np_t, torch_t = (np.float64, "float64") if f64 else (np.float32, "float32")
+    x, px, mem = _prep(x, np_t, torch_t)
     a = np.ascontiguousarray(a, dtype=np.float64)
     b = np.ascontiguousarray(b, dtype=np.float64)
     if a.size != b.size:
@@ -206,7 +228,7 @@ def iir(x, a, b, c0: float = 1.0, d0: float = 0.0, state=None, mode: str = "auto
     poles = a.size - 1
     n = x.shape[-1]
     channels = int(np.prod(x.shape[:-1])) if x.ndim > 1 else 1
-    y = _out(out, x, tuple(x.shape), np.float32, "float32")
+    y = _out(out, x, tuple(x.shape), np_t, torch_t)
     pstate = None
     if state is not None:
         if _is_torch(state) != _is_torch(x):
@@ -217,10 +239,27 @@ def iir(x, a, b, c0: float = 1.0, d0: float = 0.0, state=None, mode: str = "auto
         elif not (state.flags.c_contiguous and state.dtype == np.float64 and state.size == channels * 2 * poles):
             raise capi.DspGpuError(capi.EINVAL, "state must be contiguous float64 [channels, 2*poles]")
         pstate = _ptr(state)
+    fn = capi.lib().dsp_gpu_iir_f64 if f64 else capi.lib().dsp_gpu_iir
     with _on_device(x):
-        capi.check(capi.lib().dsp_gpu_iir(px, _ptr(y), channels, n, a.ctypes.data, b.ctypes.data, poles, float(c0),
-                                          float(d0), pstate, _IIR_MODES[mode], mem, _stream_of(x)))
+        capi.check(fn(px, _ptr(y), channels, n, a.ctypes.data, b.ctypes.data, poles, float(c0), float(d0), pstate,
+                      _IIR_MODES[mode], mem, _stream_of(x)))
     return y
+
+
+def iir(x, a, b, c0: float = 1.0, d0: float = 0.0, state=None, mode: str = "auto", out=None):
+    """IIR recursion with feedback ADDED (coefficients.h:106-130), fp32 samples.
+
+    state: [channels, 2*poles] float64 {x[t-1..t-poles], v[t-1..t-poles]}, updated in place
+    (the reference's x[]/y[] history, coefficients.h:11-12).  mode "batch_ref": the reference's own arithmetic,
+    bit for bit (float accumulator for the generic section, the all-double BiQuad for two poles)."""
+    return _iir_any(x, False, a, b, c0, d0, state, mode, out)
+
+
+def iir_f64(x, a, b, c0: float = 1.0, d0: float = 0.0, state=None, mode: str = "auto", out=None):
+    """The same on double samples: Coefficients<P>::operator()(const SampleBuffer<double>&), the instantiation every
+    in-repo caller of the reference uses (eval/recursive_filters/main.cpp:35).  One lane per channel ("scan" is
+    unsupported, "auto" runs "batch")."""
+    return _iir_any(x, True, a, b, c0, d0, state, mode, out)
 
 
 def iir_settle(a, b) -> int:
@@ -236,11 +275,13 @@ def iir_settle(a, b) -> int:
     return int(out.value)
 
 
-def iir_multi(x, a, b, c0=None, d0=None, state=None, out=None):
+def iir_multi(x, a, b, c0=None, d0=None, state=None, out=None, mode: str = "batch", f64: bool = False):
     """Filter bank: channel k runs its own Coefficients (a[k], b[k], c0[k], d0[k]); a, b [channels, poles+1]
     float64, c0/d0 [channels] float64 or None (1 and 0), all living where x lives.  Block-wise form of a
-    retuned filter (eval/signals/wind_generator.h:150-167): call per block with new coefficients, carry `state`."""
-    x, px, mem = _prep(x, np.float32, "float32")
+    retuned filter (eval/signals/wind_generator.h:150-167): call per block with new coefficients, carry `state`.
+    f64: double samples; mode "batch_ref": the reference's own arithmetic (dsp_gpu_iir_multi_ex)."""
+    np_t, torch_t = (np.float64, "float64") if f64 else (np.float32, "float32")
+    x, px, mem = _prep(x, np_t, torch_t)
     n = x.shape[-1]
     channels = int(np.prod(x.shape[:-1])) if x.ndim > 1 else 1
     poles = a.shape[-1] - 1
@@ -259,10 +300,14 @@ def iir_multi(x, a, b, c0=None, d0=None, state=None, out=None):
     pa, pb = chk(a, channels * (poles + 1), "a"), chk(b, channels * (poles + 1), "b")
     pc0, pd0 = chk(c0, channels, "c0"), chk(d0, channels, "d0")
     pstate = chk(state, channels * 2 * poles, "state")
-    y = _out(out, x, tuple(x.shape), np.float32, "float32")
+    y = _out(out, x, tuple(x.shape), np_t, torch_t)
     with _on_device(x):
-        capi.check(capi.lib().dsp_gpu_iir_multi(px, _ptr(y), channels, n, pa, pb, poles, pc0, pd0, pstate, mem,
-                                                _stream_of(x)))
+        if not f64 and mode == "batch":
+            capi.check(capi.lib().dsp_gpu_iir_multi(px, _ptr(y), channels, n, pa, pb, poles, pc0, pd0, pstate, mem,
+                                                    _stream_of(x)))
+        else:
+            capi.check(capi.lib().dsp_gpu_iir_multi_ex(px, _ptr(y), capi.F64 if f64 else capi.F32, channels, n, pa, pb,
+                                                       poles, pc0, pd0, pstate, _IIR_MODES[mode], mem, _stream_of(x)))
     return y
 
 

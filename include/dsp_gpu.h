@@ -69,6 +69,20 @@ extern "C" {
 #define DSP_GPU_IIR_AUTO  0 /* SCAN below 24,576 channels of >= 2,048 samples (and <= 8 poles), else BATCH */
 #define DSP_GPU_IIR_BATCH 1 /* one thread per channel, channels in parallel          */
 #define DSP_GPU_IIR_SCAN  2 /* block-parallel linear-recurrence scan inside a channel */
+#define DSP_GPU_IIR_BATCH_REF 3 /* BATCH in the REFERENCE'S OWN ARITHMETIC, operation for operation and in its order, with no
+                                   fused multiply-adds: the generic section (coefficients.h:106-130) accumulates in the SAMPLE
+                                   type -- with fp32 samples the accumulator is rounded to float after every `+=`, histories
+                                   stay double, output = SampleType(acc*c0 + in*d0) -- and poles == 2 is the reference's
+                                   Coefficients<2> = BiQuad (coefficients.h:172-182, all double).  Bit-identical to the
+                                   reference for float and double samples; AUTO never picks it (AUTO / BATCH / SCAN compute in
+                                   double with fused multiply-adds: <= 2e-6 from the reference's double instantiation, but for
+                                   a filter as ill-conditioned as lowPassFilter<4>(0.01) 2.5e-3 from what its float
+                                   instantiation returns, which is itself that far from its double one).  The dependency
+                                   chain per sample is 2*poles + 1 operations instead of one: slower, all four SIMDs used. */
+
+/* sample types of the entry points that take either (void pointers) */
+#define DSP_GPU_F32 0
+#define DSP_GPU_F64 1
 
 /*
  * Batched complex FFT.  Replaces dsp::fft0<type>(in, out, log2n) (fft.h:31-55) for
@@ -129,6 +143,16 @@ int dsp_gpu_fft_real_batch(const float *in, size_t n_in, size_t in_stride, void 
  */
 int dsp_gpu_convolve(const float *x, float *y, size_t channels, size_t n, const float *taps,
                      int ntaps, int mode, int mem, void *stream);
+/*
+ * The same filter on DOUBLE samples with DOUBLE taps: SincFilter<>::apply(SampleBuffer<double>&) (filter.h:123-140), the
+ * instantiation the reference's own callers use (eval/windowed_sinc_filter/main.cpp:105, eval/filter_compare/main.cpp:11)
+ * with the kernel as dsp::sinc returns it (std::vector<double>, dsp.h:47-79 -- no narrowing to fp32).  Time domain on the
+ * double matrix cores (v_mfma_f64_16x16x4_f64), products and sums exact double fmas: the result differs from the
+ * reference's loop only by the order of the sum (<= 1e-14 relative L2).  1 <= ntaps <= 4096; modes DSP_GPU_CONV_AUTO and
+ * DSP_GPU_CONV_DIRECT (DSP_GPU_CONV_OVERLAP_SAVE: DSP_GPU_EUNSUPPORTED -- the frequency-domain form is the fp32 path's).
+ */
+int dsp_gpu_convolve_f64(const double *x, double *y, size_t channels, size_t n, const double *taps,
+                         int ntaps, int mode, int mem, void *stream);
 
 /*
  * Streaming FIR: the same filter fed in chunks with the input tail carried between calls (the FIR
@@ -157,6 +181,10 @@ int dsp_gpu_convolve_stream(const float *x, float *y, size_t channels, size_t n,
  */
 int dsp_gpu_moving_average(const float *x, float *y, size_t channels, size_t n, int npoints,
                            int mem, void *stream);
+/* MovingAverageFilter::apply(SampleBuffer<double>&) (eval/moving_average_filter_demo/main.cpp:14 filters doubles): the same
+ * kernel on double samples, sums in double, the mean by division as in the reference (filter.h:93,97). */
+int dsp_gpu_moving_average_f64(const double *x, double *y, size_t channels, size_t n, int npoints,
+                               int mem, void *stream);
 
 /*
  * IIR recursion.  Replaces dsp::Coefficients<Poles>::operator()(const SampleBuffer&)
@@ -166,7 +194,10 @@ int dsp_gpu_moving_average(const float *x, float *y, size_t channels, size_t n, 
  * a, b: HOST pointers to poles+1 doubles (b[0] ignored), as produced by the designers in
  * recursive_filters.h.  1 <= poles <= 20 (Coefficients<2..20>, recursive_filters.h:30-31); SCAN mode
  * up to 8 poles (AUTO runs longer sections in BATCH).  Channel-major x[ch][n], y[ch][n].
- * Arithmetic and history are double, as in the reference (coefficients.h:9-12); samples are fp32.
+ * Arithmetic and history are double, as in the reference (coefficients.h:9-12); samples are fp32
+ * (dsp_gpu_iir) or double (dsp_gpu_iir_f64: SampleBuffer<double>, the type every in-repo caller of the reference
+ * filters -- eval/recursive_filters/main.cpp:35; one lane per channel only: SCAN is DSP_GPU_EUNSUPPORTED there and
+ * AUTO runs BATCH).  DSP_GPU_IIR_BATCH_REF reproduces the reference bit for bit (see the mode's comment).
  * `state` (may be NULL = start from rest, nothing written back) is [ch][2*poles] DOUBLES,
  * {x[t-1..t-poles], v[t-1..t-poles]} per channel, read before and written after the call:
  * it is the reference's x[]/y[] history (coefficients.h:11-12) made explicit so a long
@@ -176,6 +207,9 @@ int dsp_gpu_moving_average(const float *x, float *y, size_t channels, size_t n, 
 int dsp_gpu_iir(const float *x, float *y, size_t channels, size_t n, const double *a,
                 const double *b, int poles, double c0, double d0, double *state, int mode, int mem,
                 void *stream);
+int dsp_gpu_iir_f64(const double *x, double *y, size_t channels, size_t n, const double *a,
+                    const double *b, int poles, double c0, double d0, double *state, int mode, int mem,
+                    void *stream);
 
 /*
  * How long a filter remembers: the number of samples (a multiple of 64) after which the response to ANY initial state
@@ -198,6 +232,12 @@ int dsp_gpu_iir_settle(const double *a, const double *b, int poles, size_t *samp
  */
 int dsp_gpu_iir_multi(const float *x, float *y, size_t channels, size_t n, const double *a, const double *b,
                       int poles, const double *c0, const double *d0, double *state, int mem, void *stream);
+/* The same for either sample type (x, y: float or double arrays by `sample_type` = DSP_GPU_F32 / DSP_GPU_F64) and with
+ * the arithmetic chosen by `mode`: DSP_GPU_IIR_AUTO / DSP_GPU_IIR_BATCH (double, fused multiply-adds) or
+ * DSP_GPU_IIR_BATCH_REF (the reference's own, bit for bit: coefficients.h:106-130, poles == 2: :172-182). */
+int dsp_gpu_iir_multi_ex(const void *x, void *y, int sample_type, size_t channels, size_t n, const double *a,
+                         const double *b, int poles, const double *c0, const double *d0, double *state, int mode,
+                         int mem, void *stream);
 
 /*
  * A band-pass / band-reject BiQuad RETUNED AT EVERY SAMPLE.  Replaces the loop of eval/signals/wind_generator.h:150-167

@@ -29,12 +29,19 @@ def test_golden_chebyshev(ops, dev, golden, tag, mode):
     x = golden["iir_noise_in"]
     a, b = golden[f"cheby_{tag}_a"], golden[f"cheby_{tag}_b"]
     got = ops.iir(torch.from_numpy(x).to(dev), a, b, mode=mode).cpu().numpy()
-    # fc = 0.01: four poles clustered at z = 1.  The scan carries its states in double-double there; the
-    # reference's own float instantiation is 2.5e-3 away from its double one (it rounds the fed-back
-    # output to float at every step), hence the widened second bound.
+    # The fast modes compute in double with fused multiply-adds: parity is against the reference's DOUBLE instantiation
+    # on the same float-exact samples, to fp32 output rounding.  (fc = 0.01, `lp4_lo`: four poles clustered at z = 1; the
+    # scan carries its states in double-double there.)
     assert rel_l2(got, golden[f"cheby_{tag}_y64"]) <= TIGHT
-    ref32_own = rel_l2(golden[f"cheby_{tag}_y32"].astype(np.float64), golden[f"cheby_{tag}_y64"])
-    assert rel_l2(got, golden[f"cheby_{tag}_y32"].astype(np.float64)) <= TOL + 2 * ref32_own
+    # Against the reference's FLOAT instantiation (`_y32`, whose accumulator is rounded to float at every `+=`,
+    # SURVEY.md Q12) the bar is north_star's 1e-4 with no allowance; the mode that reproduces that instantiation is
+    # DSP_GPU_IIR_BATCH_REF, bit for bit for every fixture, lp4_lo included.  (The fast modes are inside 1e-4 of `_y32`
+    # wherever the float instantiation is itself inside 1e-4 of the double one -- every fixture but lp4_lo, where the
+    # reference's float result is 2.5e-3 from its own double result -- and that is asserted for them too.)
+    ref = ops.iir(torch.from_numpy(x).to(dev), a, b, mode="batch_ref").cpu().numpy()
+    assert np.array_equal(ref, golden[f"cheby_{tag}_y32"])
+    if tag != "lp4_lo":
+        assert rel_l2(got, golden[f"cheby_{tag}_y32"].astype(np.float64)) <= TOL
     assert np.array_equal(got, ops.iir(x, a, b, mode=mode))  # host-pointer path
 
 
