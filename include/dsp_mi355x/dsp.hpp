@@ -2,8 +2,9 @@
 //
 // Header-only host layer: every function below keeps the NAME, argument order and result
 // convention of the reference function it stands in for (file:line relative to the reference's
-// dsp/include/dsp/), in fp32 and with an optional batch/channel count, and forwards the samples
-// to libdsp_gpu.so (include/dsp_gpu.h).  Nothing is computed on the CPU except the filter
+// dsp/include/dsp/), for SampleBuffer<float> AND SampleBuffer<double> (sample_buffer.h:20; every in-repo caller of
+// the reference filters doubles) and with an optional batch/channel count, and forwards the samples
+// to libdsp_gpu.so (include/dsp_gpu.h): float buffers to the fp32 entry points, double buffers to the *_f64 ones.  Nothing is computed on the CPU except the filter
 // *designs* (taps, coefficients), which the reference also computes once, in double, in
 // microseconds (dsp.h:47-79, recursive_filters.h:24-263).
 //
@@ -25,8 +26,9 @@
 // (assert on argument ranges, one std::runtime_error in convolve) there are no error codes; a
 // failing C-ABI call throws std::runtime_error carrying dsp_gpu_last_error_string().
 //
-// Link with -ldsp_gpu (dsp_amd/lib).  Define DSP_MI355X_AS_DSP before including to get
-// `namespace dsp = dsp_mi355x;` when the reference's headers are not in the translation unit.
+// Link with -ldsp_gpu (dsp_amd/lib).  The names live in `namespace dsp` like the reference's (an alias of
+// dsp_mi355x, so that a caller of the reference -- tests/cpp/reference_callers_check.cpp -- compiles unchanged); define
+// DSP_MI355X_NO_DSP_ALIAS before including when the reference's own headers are in the same translation unit.
 #pragma once
 
 #include <array>
@@ -39,6 +41,7 @@
 #include <stdexcept>
 #include <string>
 #include <type_traits>
+#include <utility>
 #include <vector>
 
 #include "../dsp_gpu.h"
@@ -258,13 +261,24 @@ auto mptr(Buffer &b) -> decltype(&b[0]) { return b.size() ? &b[0] : nullptr; }
 inline std::vector<float> narrow(const std::vector<double> &v) { return std::vector<float>(v.begin(), v.end()); }
 
 template <typename Buffer>
-Buffer fir(const Buffer &x, const std::vector<float> &taps, int mode, size_t channels) {
+using sample_t = std::remove_cv_t<std::remove_reference_t<decltype(std::declval<const Buffer &>()[0])>>;
+
+// double buffers: double taps, time domain on the double matrix cores whatever `mode` says (<= 4096 taps);
+// float buffers: the fp32 path with the kernel narrowed to float
+template <typename Buffer>
+Buffer fir(const Buffer &x, const std::vector<double> &kernel, const std::vector<float> &taps, int mode, size_t channels) {
     Buffer y(x.size());
-    if (x.size() == 0 || taps.empty()) return y;
+    if (x.size() == 0 || kernel.empty()) return y;
     assert(channels >= 1 && x.size() % channels == 0);
-    check(dsp_gpu_convolve(cptr(x), mptr(y), channels, x.size() / channels, taps.data(), static_cast<int>(taps.size()),
-                           mode, DSP_GPU_MEM_HOST, nullptr),
-          "convolve");
+    if constexpr (std::is_same_v<sample_t<Buffer>, double>) {
+        check(dsp_gpu_convolve_f64(cptr(x), mptr(y), channels, x.size() / channels, kernel.data(), static_cast<int>(kernel.size()),
+                                   DSP_GPU_CONV_AUTO, DSP_GPU_MEM_HOST, nullptr),
+              "convolve");
+    } else {
+        check(dsp_gpu_convolve(cptr(x), mptr(y), channels, x.size() / channels, taps.data(), static_cast<int>(taps.size()),
+                               mode, DSP_GPU_MEM_HOST, nullptr),
+              "convolve");
+    }
     return y;
 }
 }  // namespace detail
@@ -275,10 +289,11 @@ Buffer fir(const Buffer &x, const std::vector<float> &taps, int mode, size_t cha
 // first kernel.size()-1 zero.
 template <Domain domain = Domain::Time, typename Buffer, typename KernelBuffer>
 Buffer convolve(const Buffer &signal, const KernelBuffer &kernel) {
-    std::vector<float> taps(kernel.size());
-    for (size_t i = 0; i < taps.size(); ++i) taps[i] = static_cast<float>(kernel[static_cast<int>(i)]);
+    std::vector<double> taps64(kernel.size());
+    for (size_t i = 0; i < taps64.size(); ++i) taps64[i] = static_cast<double>(kernel[static_cast<int>(i)]);
     if (domain == Domain::Spacial) throw std::runtime_error("Not yet implemented!");
-    return detail::fir(signal, taps, domain == Domain::Frequency ? DSP_GPU_CONV_OVERLAP_SAVE : DSP_GPU_CONV_DIRECT, 1);
+    return detail::fir(signal, taps64, detail::narrow(taps64),
+                       domain == Domain::Frequency ? DSP_GPU_CONV_OVERLAP_SAVE : DSP_GPU_CONV_DIRECT, 1);
 }
 
 namespace filter {
@@ -296,9 +311,14 @@ struct MovingAverageFilter {
     Buffer apply(const Buffer &sampleBuffer, size_t channels = 1) const {
         Buffer y(sampleBuffer.size());
         if (sampleBuffer.size() == 0) return y;
-        check(dsp_gpu_moving_average(detail::cptr(sampleBuffer), detail::mptr(y), channels, sampleBuffer.size() / channels,
-                                     static_cast<int>(m_numPoints), DSP_GPU_MEM_HOST, nullptr),
-              "MovingAverageFilter::apply");
+        if constexpr (std::is_same_v<detail::sample_t<Buffer>, double>)
+            check(dsp_gpu_moving_average_f64(detail::cptr(sampleBuffer), detail::mptr(y), channels, sampleBuffer.size() / channels,
+                                             static_cast<int>(m_numPoints), DSP_GPU_MEM_HOST, nullptr),
+                  "MovingAverageFilter::apply");
+        else
+            check(dsp_gpu_moving_average(detail::cptr(sampleBuffer), detail::mptr(y), channels, sampleBuffer.size() / channels,
+                                         static_cast<int>(m_numPoints), DSP_GPU_MEM_HOST, nullptr),
+                  "MovingAverageFilter::apply");
         return y;
     }
     template <typename Buffer>
@@ -323,7 +343,7 @@ struct SincFilter {
     Buffer apply(const Buffer &sampleBuffer, size_t channels = 1, int mode = DSP_GPU_CONV_DIRECT) const {
         // the direct form stops at 4096 taps; longer kernels go through the (partitioned) overlap-save path
         if (mode == DSP_GPU_CONV_DIRECT && m_taps.size() > 4096) mode = DSP_GPU_CONV_OVERLAP_SAVE;
-        return detail::fir(sampleBuffer, m_taps, mode, channels);
+        return detail::fir(sampleBuffer, m_kernel, m_taps, mode, channels);
     }
     std::vector<double> kernel() const { return m_kernel; }
 
@@ -333,15 +353,32 @@ struct SincFilter {
     Buffer stream(const Buffer &block, int mode = DSP_GPU_CONV_DIRECT) {
         Buffer y(block.size());
         if (block.size() == 0 || m_taps.empty()) return y;
-        m_history.resize(m_taps.size() - 1);
-        check(dsp_gpu_convolve_stream(detail::cptr(block), detail::mptr(y), 1, block.size(), m_taps.data(),
-                                      static_cast<int>(m_taps.size()), m_history.empty() ? nullptr : m_history.data(),
-                                      m_position, mode, DSP_GPU_MEM_HOST, nullptr),
-              "SincFilter::stream");
+        if constexpr (std::is_same_v<detail::sample_t<Buffer>, double>) {
+            // double blocks: the one-shot double filter over (carried tail ++ block); the tail lives in the object
+            const size_t order = m_kernel.size() - 1;
+            m_history64.resize(order, 0.0);
+            std::vector<double> in(m_history64), out(order + block.size());
+            for (size_t i = 0; i < block.size(); ++i) in.push_back(block[static_cast<int>(i)]);
+            check(dsp_gpu_convolve_f64(in.data(), out.data(), 1, in.size(), m_kernel.data(), static_cast<int>(m_kernel.size()),
+                                       DSP_GPU_CONV_AUTO, DSP_GPU_MEM_HOST, nullptr),
+                  "SincFilter::stream");
+            for (size_t i = 0; i < block.size(); ++i)  // outputs before the stream's first full window stay zero (filter.h:126,133)
+                y[static_cast<int>(i)] = m_position + i < order ? 0.0 : out[order + i];
+            m_history64.assign(in.end() - static_cast<std::ptrdiff_t>(order), in.end());
+        } else {
+            m_history.resize(m_taps.size() - 1);
+            check(dsp_gpu_convolve_stream(detail::cptr(block), detail::mptr(y), 1, block.size(), m_taps.data(),
+                                          static_cast<int>(m_taps.size()), m_history.empty() ? nullptr : m_history.data(),
+                                          m_position, mode, DSP_GPU_MEM_HOST, nullptr),
+                  "SincFilter::stream");
+        }
         m_position += block.size();
         return y;
     }
-    void reset() { m_position = 0; }
+    void reset() {
+        m_position = 0;
+        m_history64.clear();
+    }
 
   private:
     void design() {
@@ -352,6 +389,7 @@ struct SincFilter {
     std::vector<double> m_kernel{};
     std::vector<float> m_taps{};
     std::vector<float> m_history{};
+    std::vector<double> m_history64{};
     unsigned long long m_position{0};
     size_t m_length{0};
 };
@@ -371,7 +409,10 @@ struct Coefficients {
     double d0{0};
     static constexpr size_t poles = Poles;
 
-    // coefficients.h:88-104: filter the whole buffer, continuing from (and updating) x[] / y[]
+    // coefficients.h:88-104: filter the whole buffer, continuing from (and updating) x[] / y[].  SampleBuffer<float> or
+    // SampleBuffer<double>.  mode DSP_GPU_IIR_BATCH_REF reproduces the reference's arithmetic bit for bit (for float
+    // buffers the generic section then accumulates in float, coefficients.h:108-118); the default computes in double
+    // with fused multiply-adds.
     template <typename Buffer>
     Buffer operator()(const Buffer &input, int mode = DSP_GPU_IIR_AUTO) {
         assert(b[0] == 0);
@@ -382,9 +423,14 @@ struct Coefficients {
             st[i] = x[i + 1];
             st[Poles + i] = y[i + 1];
         }
-        check(dsp_gpu_iir(detail::cptr(input), detail::mptr(output), 1, input.size(), a.data(), b.data(), static_cast<int>(Poles), c0,
-                          d0, st.data(), mode, DSP_GPU_MEM_HOST, nullptr),
-              "Coefficients::operator()");
+        if constexpr (std::is_same_v<detail::sample_t<Buffer>, double>)
+            check(dsp_gpu_iir_f64(detail::cptr(input), detail::mptr(output), 1, input.size(), a.data(), b.data(), static_cast<int>(Poles),
+                                  c0, d0, st.data(), mode, DSP_GPU_MEM_HOST, nullptr),
+                  "Coefficients::operator()");
+        else
+            check(dsp_gpu_iir(detail::cptr(input), detail::mptr(output), 1, input.size(), a.data(), b.data(), static_cast<int>(Poles), c0,
+                              d0, st.data(), mode, DSP_GPU_MEM_HOST, nullptr),
+                  "Coefficients::operator()");
         for (size_t i = 0; i < Poles; ++i) {
             x[i + 1] = st[i];
             y[i + 1] = st[Poles + i];
@@ -411,6 +457,12 @@ struct Coefficients {
                int mode = DSP_GPU_IIR_AUTO) const {
         check(dsp_gpu_iir(in, out, channels, n, a.data(), b.data(), static_cast<int>(Poles), c0, d0, state, mode,
                           DSP_GPU_MEM_HOST, nullptr),
+              "Coefficients::apply");
+    }
+    void apply(const double *in, double *out, size_t channels, size_t n, double *state = nullptr,
+               int mode = DSP_GPU_IIR_AUTO) const {
+        check(dsp_gpu_iir_f64(in, out, channels, n, a.data(), b.data(), static_cast<int>(Poles), c0, d0, state, mode,
+                              DSP_GPU_MEM_HOST, nullptr),
               "Coefficients::apply");
     }
 };
@@ -525,10 +577,14 @@ Buffer bandPassSwept(BiQuad &filter, const Buffer &input, const Sweep &centerFre
     std::vector<float> fc(input.size());
     for (size_t i = 0; i < fc.size(); ++i) fc[i] = static_cast<float>(centerFrequency[static_cast<int>(i)]);
     std::array<double, 4> st{filter.x[1], filter.x[2], filter.y[1], filter.y[2]};
-    check(dsp_gpu_biquad_swept(::dsp_mi355x::detail::cptr(input), fc.data(), ::dsp_mi355x::detail::mptr(output), 1, input.size(),
+    // (the wind generator's samples are float, wind_generator.h:150-167; other buffer types ride through a float copy)
+    std::vector<float> xin(input.size()), yout(input.size());
+    for (size_t i = 0; i < xin.size(); ++i) xin[i] = static_cast<float>(input[static_cast<int>(i)]);
+    check(dsp_gpu_biquad_swept(xin.data(), fc.data(), yout.data(), 1, input.size(),
                                input.size(), reject ? DSP_GPU_SWEPT_BANDREJECT : DSP_GPU_SWEPT_BANDPASS, bandwidth, st.data(),
                                DSP_GPU_MEM_HOST, nullptr),
           "bandPassSwept");
+    for (size_t i = 0; i < yout.size(); ++i) output[static_cast<int>(i)] = yout[i];
     filter.x[1] = st[0];
     filter.x[2] = st[1];
     filter.y[1] = st[2];
@@ -582,6 +638,6 @@ inline BiQuad peakingFilter(double frequency, double gain, double q_) {  // recu
 }  // namespace recursive
 }  // namespace dsp_mi355x
 
-#ifdef DSP_MI355X_AS_DSP
-namespace dsp = dsp_mi355x;
+#ifndef DSP_MI355X_NO_DSP_ALIAS
+namespace dsp = dsp_mi355x;  // (DSP_MI355X_AS_DSP, which used to ask for this, is still accepted and no longer needed)
 #endif

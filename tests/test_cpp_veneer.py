@@ -101,6 +101,56 @@ def test_veneer_on_gpu(tmp_path, orc, golden, dev):
     assert rel_l2(rd("iir_rows.f32", np.float32).reshape(4, -1), orc.iir(rows, golden["cheby_lp4_a"], golden["cheby_lp4_b"])) <= 2e-6
 
 
+@pytest.mark.gpu
+def test_reference_callers_on_gpu(tmp_path, orc, dev):
+    """tests/cpp/reference_callers_check.cpp: the numeric work of eval/filter_compare, eval/recursive_filters (createDate /
+    applyFilter), eval/moving_average_filter_demo and eval/windowed_sinc_filter on SampleBuffer<double>, written against
+    `namespace dsp` exactly as those programs call the reference, against the oracle's double functions."""
+    exe = os.path.join(ROOT, "tests", "cpp", "reference_callers_check")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "cpp"), "reference_callers_check"], check=True, capture_output=True)
+    d = str(tmp_path)
+    rng = np.random.default_rng(2024)
+    noise = rng.standard_normal(5000)
+    noise.tofile(os.path.join(d, "noise.f64"))
+    p = subprocess.run([exe, d], capture_output=True, text=True, timeout=110)
+    assert p.returncode == 0, p.stderr
+    rd = lambda name: np.fromfile(os.path.join(d, name), dtype=np.float64)
+
+    imp = np.zeros(401)
+    imp[300] = 1.0
+    assert np.array_equal(rd("filter_compare.f64"), orc.fir(imp, orc.sinc(0.14, 200)))  # one product per output: exact
+
+    f, bw, g = float(np.float32(0.25)), float(np.float32(0.006)), 1.0  # the callers hold these in float
+    designs = {
+        "low_pass": orc.chebyshev(f, 2) + (1.0, 0.0),
+        "high_pass": orc.chebyshev(f, 2, highpass=True) + (1.0, 0.0),
+        "band_pass": orc.biquad_design("bandpass", f, bw),
+        "band_reject": orc.biquad_design("bandreject", f, bw),
+        "low_shelf": orc.biquad_design("lowshelf", f, g),
+        "high_shelf": orc.biquad_design("highshelf", f, g),
+        "peaking": orc.biquad_design("peaking", f, g, bw),
+    }
+    impulse = np.zeros(1024)
+    impulse[512] = 1.0
+    for kind, (a, b, c0, d0) in designs.items():
+        want = orc.biquad(impulse, a, b, c0, d0)
+        got = rd(f"recursive_{kind}_response.f64")
+        assert rel_l2(got, want) <= 2e-12, kind
+        mag = np.abs(orc.fft_real(got, 1024))
+        assert rel_l2(rd(f"recursive_{kind}_magnitude.f64"), mag) <= 1e-13, kind
+
+    a4, b4 = orc.chebyshev(0.1, 4)
+    assert rel_l2(rd("noise_lp4.f64"), orc.iir(noise, a4, b4)) <= 2e-12
+    assert np.array_equal(rd("noise_lp4_ref.f64"), orc.iir(noise, a4, b4))          # DSP_GPU_IIR_BATCH_REF: bit for bit
+    a, b, c0, d0 = designs["peaking"]
+    assert np.array_equal(rd("noise_peaking_ref.f64"), orc.biquad(noise, a, b, c0, d0))
+    for size in (1, 8, 51):
+        assert rel_l2(rd(f"mavg_{size}.f64"), orc.moving_average(noise, size)) <= 1e-12, size
+    assert rel_l2(rd("sinc_hp.f64"), orc.fir(noise, orc.sinc(0.2, 200, inversion="inversion"))) <= 1e-13
+    assert rel_l2(rd("sinc_lp_streamed.f64"), orc.fir(noise, orc.sinc(0.14, 200))) <= 1e-13
+
+
 def test_swept_cos_matches_libm():
     """dsp_amd/csrc/swept_cos.h (the cosine inside the per-sample band-pass design, recursive_filters.h:169) compiled
     for the host, against the C library's cos over 2^24 frequencies in [0, 0.5], the quadrant edges and tiny
