@@ -49,6 +49,7 @@ struct TapSlot {
     hipEvent_t ready = nullptr;     // taps + spectra built (recorded on the building stream)
     hipEvent_t last_use = nullptr;  // recorded by every call after its kernels
     bool used = false;
+    bool used_once = false;  // last_use has been recorded at least once
     int pins = 0;
     unsigned long long stamp = 0;  // LRU clock
 };
@@ -154,7 +155,11 @@ void release_taps(const TapLease &lease, hipStream_t s) {
     if (lease.slot < 0) return;
     std::lock_guard<std::mutex> lock(g_mutex);
     TapSlot &e = g_dev[lease.dev].taps[lease.slot];
+    // `last_use` is one event re-recorded by every call on whatever stream it used: make `s` wait for the previous
+    // record first, so that the new record covers every earlier use on every stream (a take-over waits on it alone)
+    if (e.used_once) (void)hipStreamWaitEvent(s, e.last_use, 0);
     (void)hipEventRecord(e.last_use, s);
+    e.used_once = true;
     --e.pins;
 }
 
@@ -385,7 +390,9 @@ int dsp_gpu_fft_real_batch(const float *in, size_t n_in, size_t in_stride, void 
 
 // shared by the one-shot and the streaming form; `history` == nullptr: one-shot (filter.h:123-140)
 // Device buffers that overlap would have one workgroup overwrite samples another still has to read (FIR history,
-// window and warm-up samples reach back across tile borders); host buffers are staged and may alias.
+// window and warm-up samples reach back across tile borders); host buffers are staged and may alias or overlap in any
+// way (run_host_job stages the whole input before it writes anything back unless the two are the same array with equal
+// unit sizes, the one case its pipeline handles chunk by chunk).
 static bool device_overlap(const void *a, const void *b, size_t bytes, int mem) {
     if (mem != DSP_GPU_MEM_DEVICE) return false;
     const char *p = static_cast<const char *>(a), *q = static_cast<const char *>(b);

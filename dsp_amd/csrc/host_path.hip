@@ -53,7 +53,14 @@ public:
                 if (tasks[i].bytes) std::memcpy(tasks[i].dst, tasks[i].src, tasks[i].bytes);
             return;
         }
-        std::unique_lock<std::mutex> call(call_mutex_);  // one parallel copy at a time
+        // one parallel copy at a time; a caller that finds the pool busy (another device's host thread is inside) copies
+        // its own pieces inline rather than queueing behind it
+        std::unique_lock<std::mutex> call(call_mutex_, std::try_to_lock);
+        if (!call.owns_lock()) {
+            for (int i = 0; i < ntasks; ++i)
+                if (tasks[i].bytes) std::memcpy(tasks[i].dst, tasks[i].src, tasks[i].bytes);
+            return;
+        }
         {
             std::lock_guard<std::mutex> lock(m_);
             pieces_.clear();
@@ -126,7 +133,10 @@ struct Pipe {
     size_t cap_in = 0, cap_out = 0;
     bool ready = false;
 };
-std::mutex g_pipe_mutex;  // held for the whole of a host-route call: they share the staging workspaces anyway
+// One per device, held for the whole of a host-route call on that device (such calls share the device's staging
+// workspaces and ring slots); host threads driving DIFFERENT devices -- the header's intended multi-GPU use -- do not
+// serialise on each other.
+std::mutex g_pipe_mutex[kMaxDev];
 Pipe g_pipe[kMaxDev];
 
 int pipe_init(Pipe &p) {
@@ -173,7 +183,7 @@ bool page_locked(const void *p) {
 
 void release_host_pipes(int dev) {  // with device `dev` current and idle (dsp_gpu_shutdown)
     if (dev < 0 || dev >= kMaxDev) return;
-    std::lock_guard<std::mutex> lock(g_pipe_mutex);
+    std::lock_guard<std::mutex> lock(g_pipe_mutex[dev]);
     Pipe &p = g_pipe[dev];
     if (!p.ready) return;
     for (int i = 0; i < kSlots; ++i) {
@@ -189,8 +199,9 @@ void release_host_pipes(int dev) {  // with device `dev` current and idle (dsp_g
 }
 
 bool host_pipe_in_use(int dev) {
-    std::lock_guard<std::mutex> lock(g_pipe_mutex);
-    return dev >= 0 && dev < kMaxDev && g_pipe[dev].ready;
+    if (dev < 0 || dev >= kMaxDev) return false;
+    std::lock_guard<std::mutex> lock(g_pipe_mutex[dev]);
+    return g_pipe[dev].ready;
 }
 
 int run_host_job(const HostJob &job, hipStream_t s) {
@@ -201,7 +212,7 @@ int run_host_job(const HostJob &job, hipStream_t s) {
     const size_t aux_bytes = job.aux ? job.aux_bytes : 0;
     auto up16 = [](size_t v) { return (v + 15) & ~static_cast<size_t>(15); };
 
-    std::lock_guard<std::mutex> lock(g_pipe_mutex);
+    std::lock_guard<std::mutex> lock(g_pipe_mutex[dev]);
     Pipe &p = g_pipe[dev];
     if (int rc = pipe_init(p)) return rc;
 
@@ -243,6 +254,15 @@ int run_host_job(const HostJob &job, hipStream_t s) {
     size_t chunks = 1;
     if (job.units >= 2 && job.in_total + out_total >= kPipelineFrom)
         chunks = std::min<size_t>(job.units, std::max<size_t>(2, (std::max(job.in_total, out_total) + kChunkBytes - 1) / kChunkBytes));
+    // Caller buffers that overlap: the pipeline writes chunk i-2 of `out` while later chunks of `in` are still unread.
+    // That is safe when the two are the SAME array with equal unit sizes (chunk k's output lands on chunk k's input,
+    // already staged); for any other overlap (y = x + k, or in == out with in_unit != out_unit: the real-input FFT)
+    // everything is staged in before anything is written back, as the unpipelined route did.
+    {
+        const char *i0 = job.in, *i1 = job.in + job.in_total, *o0 = job.out, *o1 = job.out + out_total;
+        const bool overlap = i0 < o1 && o0 < i1;
+        if (overlap && !(i0 == o0 && job.in_unit == job.out_unit)) chunks = 1;
+    }
     auto unit_of = [&](size_t k) { return job.units * k / chunks; };
     auto in_off = [&](size_t u) { return std::min(u * job.in_unit, job.in_total); };  // the last unit may be short
     size_t max_in = 0, max_out = 0;

@@ -124,13 +124,13 @@ def fft0_f64(x, inverse: bool = False, out=None):
     return out
 
 
-def fft(x, nf: int, inverse: bool = False, shift: bool = False):
+def fft(x, nf: int, inverse: bool = False, shift: bool = False, out=None):
     """Real-input wrapper dsp::fft (fft.h:57-83), optionally followed by dsp::shift (fft.h:85-94)."""
     x, px, mem = _prep(x, np.float32, "float32")
     n_in = x.shape[-1]
     batch = int(np.prod(x.shape[:-1])) if x.ndim > 1 else 1
     log2n = max(1, int(np.ceil(np.log2(nf))))
-    out = _empty_like(x, tuple(x.shape[:-1]) + (1 << log2n,), np.complex64, "complex64")
+    out = _out(out, x, tuple(x.shape[:-1]) + (1 << log2n,), np.complex64, "complex64")
     with _on_device(x):
         capi.check(capi.lib().dsp_gpu_fft_real_batch(px, n_in, n_in, _ptr(out), int(nf), batch,
                                                      capi.INVERSE if inverse else capi.FORWARD, int(shift), mem,

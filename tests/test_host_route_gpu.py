@@ -32,6 +32,34 @@ def test_fft_host_equals_device(ops, dev, batch, log2n):
     assert np.array_equal(y, want)
 
 
+def test_host_buffers_that_overlap_partially(ops, dev):
+    """Host buffers may overlap in any way: the pipelined route must not write chunk i-2 of `out` over input it has not
+    staged yet.  y = x shifted by five rows (equal unit sizes, different arrays), and a real-input FFT whose float rows
+    live inside the complex output array (in == out, in_unit != out_unit)."""
+    import torch
+    rng = np.random.default_rng(12)
+    buf = np.zeros((705, 4096), dtype=np.complex64)
+    x = buf[5:]
+    x[...] = (rng.standard_normal((700, 4096)) + 1j * rng.standard_normal((700, 4096))).astype(np.complex64)
+    want = ops.fft0(torch.from_numpy(x.copy()).to(dev)).cpu().numpy()
+    y = buf[:700]
+    ops.fft0(x, out=y)       # 23 MiB each way: cut into chunks unless the overlap is noticed
+    assert np.array_equal(y, want)
+    buf2 = np.zeros((705, 4096), dtype=np.complex64)
+    x2 = buf2[:700]
+    x2[...] = x.copy() if False else (rng.standard_normal((700, 4096)) + 1j * rng.standard_normal((700, 4096))).astype(np.complex64)
+    want2 = ops.fft0(torch.from_numpy(x2.copy()).to(dev)).cpu().numpy()
+    ops.fft0(x2, out=buf2[5:])  # the other direction: out ahead of in
+    assert np.array_equal(buf2[5:], want2)
+
+    out = np.zeros((900, 4096), dtype=np.complex64)
+    xr = out.view(np.float32).reshape(-1)[:900 * 3000].reshape(900, 3000)
+    xr[...] = rng.standard_normal((900, 3000)).astype(np.float32)
+    want3 = ops.fft(torch.from_numpy(xr.copy()).to(dev), 3000).cpu().numpy()
+    ops.fft(xr, 3000, out=out)
+    assert np.array_equal(out, want3)
+
+
 def test_real_fft_host_rows_with_padding(ops, dev):
     import torch
     rng = np.random.default_rng(5)
