@@ -135,6 +135,46 @@ DSP_DEV void wave_transpose(c32 (&r)[kWavePoints], float *img, int lane) {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// QUAD: the same 64 x 64 transpose in HALF the LDS (16,896 B per wave), so that a CU's 160 KB hold the images of eight
+// waves -- two per SIMD.  The matrix is cut into four 32 x 32 blocks.  v_permlane32_swap_b32 (gfx950) first trades the
+// off-diagonal blocks between the two halves of the wave (lanes 32..63 of r[jj] <-> lanes 0..31 of r[32 + jj]); what is
+// left is a 32 x 32 transpose inside each (lane half, register half), done for the register halves one after the other
+// through one 32 x 33 image per lane half.  Same 64 stores + 64 loads of 8 bytes as the WIDE form, 64 swaps on top.
+constexpr int kWaveQuadRow = 33;
+constexpr int kWaveLdsQuadBytes = 2 * 32 * kWaveQuadRow * 8;
+
+// lanes 32..63 of a <-> lanes 0..31 of b
+DSP_DEV void swap_lane_halves(c32 &a, c32 &b) {
+    // (asm, not __builtin_amdgcn_permlane32_swap: with the builtin called once per component hipcc 7.2 emitted the swap
+    // of the real parts only and copied its result into the imaginary parts)
+    float ax = a.x, ay = a.y, bx = b.x, by = b.y;
+    asm("v_permlane32_swap_b32 %0, %2\n\t"
+        "v_permlane32_swap_b32 %1, %3"
+        : "+v"(ax), "+v"(ay), "+v"(bx), "+v"(by));
+    a = mk(ax, ay);
+    b = mk(bx, by);
+}
+
+DSP_DEV void wave_transpose_quad(c32 (&r)[kWavePoints], float *img, int lane) {
+    c32 *q = reinterpret_cast<c32 *>(img) + (lane >> 5) * (32 * kWaveQuadRow);
+    const int c = lane & 31;
+    c32 *wr = q + c;
+    const c32 *rd = q + c * kWaveQuadRow;
+#pragma unroll
+    for (int jj = 0; jj < 32; ++jj) swap_lane_halves(r[jj], r[32 + jj]);
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+#pragma unroll
+        for (int jj = 0; jj < 32; ++jj) wr[jj * kWaveQuadRow] = r[32 * g + jj];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int jj = 0; jj < 32; ++jj) r[32 * g + jj] = rd[jj];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
 // In: r[j] = x[lane + 64 j].  Out: r[j] = X[lane + 64 j], X[k] = sum_n x[n] exp(SIGN 2 pi i n k / 4096).
 //   n = 64 n1 + n2, k = k1 + 64 k2:
 //   X[k1 + 64 k2] = sum_n2 W64^{n2 k2} ( W4096^{n2 k1} sum_n1 x[64 n1 + n2] W64^{n1 k1} )
@@ -176,6 +216,38 @@ DSP_DEV void fft4096_wave(c32 (&r)[kWavePoints], float *img, int lane, Hook hook
     }
     wave_transpose<WIDE, WIDE>(r, img, lane);
     Dft<64, SIGN>::run(r, [&](int i) { hook(8 + i); });
+}
+
+// the same transform with the QUAD transpose (half the LDS: two waves per SIMD fit a CU)
+template <int SIGN, typename Hook>
+DSP_DEV void fft4096_wave_quad(c32 (&r)[kWavePoints], float *img, int lane, Hook hook) {
+    Dft<64, SIGN>::run(r, [&](int i) { hook(i); });
+    {
+        const c32 w = unit_root<SIGN>(static_cast<unsigned>(lane), 12);
+        c32 pb[8], pa[8];
+        pb[1] = w;
+#pragma unroll
+        for (int t = 2; t < 8; ++t) pb[t] = cmul(pb[t >> 1], pb[t - (t >> 1)]);
+        pa[1] = cmul(pb[4], pb[4]);
+#pragma unroll
+        for (int t = 2; t < 8; ++t) pa[t] = cmul(pa[t >> 1], pa[t - (t >> 1)]);
+#pragma unroll
+        for (int a = 0; a < 8; ++a) {
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                if (a == 0 && b == 0) continue;
+                const c32 tw = a == 0 ? pb[b] : (b == 0 ? pa[a] : cmul(pa[a], pb[b]));
+                r[8 * a + b] = cmul(r[8 * a + b], tw);
+            }
+        }
+    }
+    wave_transpose_quad(r, img, lane);
+    Dft<64, SIGN>::run(r, [&](int i) { hook(8 + i); });
+}
+
+template <int SIGN>
+DSP_DEV void fft4096_wave_quad(c32 (&r)[kWavePoints], float *img, int lane) {
+    fft4096_wave_quad<SIGN>(r, img, lane, [](int) {});
 }
 
 }  // namespace dspgpu
