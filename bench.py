@@ -10,12 +10,18 @@ per GPU; channels are independent, so every rank owns its own batch of the same 
 scaling, no data-path collective) and `value` = samples all ranks processed / max-over-ranks time.
 
 `secondary`    the default run also times the FIR / IIR / moving-average workloads BASELINE's metric names, each with
-               the same W warm-up and K timed steps between the same barriers.  They are timed BEFORE the headline
-               FFT (--headline-first: after it): the first memory-bound workload of a fresh process would be
-               timed while the chip is still ramping, the MFMA-bound direct FIR that goes first
-               does not care, and every figure of the line is then taken at sustained clocks.
+               the same W warm-up and K timed steps between the same barriers.  They are timed between the two
+               measurements of the headline FFT (`cold` first, `value` last): the first memory-bound workload of a
+               fresh process is timed while the chip is still ramping, the MFMA-bound direct FIR that
+               follows does not care, and every other figure of the line is then taken at sustained clocks.
 `roofline`     algorithmic bytes (or flops) of one launch / average launch time measured with
                HIP events recorded on the stream the launches go to, over the timed region.
+`step_ms`      mean of the timed region plus median and min of per-step event times (a second pass of K steps with an
+               event after every step, straight after the timed region; the timed region itself carries no extra events).
+`parity`       rel-L2 of a slice of the SAME device buffers the timed steps wrote, against the CPU oracle (the checker,
+               never the thing measured; outside the timed region; rank 0 at N=1 only, skipped by --no-cpu-baseline).
+`cold`         default run only: the headline FFT measured FIRST in the fresh process (chip still ramping, DESIGN.md
+               4.1) beside `value`, which is measured last at sustained clocks.
 `cpu_baseline` the reference's own code (oracle/_ref, kind "reference") if that library
                travelled with the tree, else the oracle restatement (kind "port"), single
                thread (the reference is single-threaded), on a bounded sample of the workload.
@@ -54,8 +60,9 @@ def parse():
     ap.add_argument("--no-secondary", action="store_true",
                     help="default fft run only: skip the FIR / IIR / moving-average workloads reported under `secondary`")
     ap.add_argument("--headline-first", action="store_true",
-                    help="default fft run only: time the headline FFT before the secondary workloads (cold chip) instead of after")
-    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the CPU baseline sample")
+                    help="default fft run only: report the headline FFT as measured FIRST (cold chip) as `value` and the "
+                         "measurement after the secondary workloads as `sustained` (default: the other way round, `cold`)")
+    ap.add_argument("--cpu-seconds", type=float, default=6.0, help="budget of the CPU baseline sample")
     ap.add_argument("--cpu-threads", type=int, default=int(os.environ.get("OMP_NUM_THREADS", "0") or 0),
                     help="also time the reference on this many host threads (0/1: skip); default $OMP_NUM_THREADS")
     return ap.parse_args()
@@ -91,6 +98,13 @@ def make_fft(torch, dev, ops, rank):
                         "batch": batch, "n": n, "sharding": "channels, no collective"},
                 bound="hbm", alg_per_unit=16.0, alg_unit="bytes/sample (8 B read + 8 B write)",
                 kernel="fft_lds_kernel<12>")
+
+    def parity(orc):  # first 8 transforms of the timed buffers against fft0 in double (fft.h:31-55)
+        k = min(8, batch)
+        want = orc.fft0(x[:k].cpu().numpy().astype(np.complex128), False)
+        return _rel_l2(out[:k].cpu().numpy(), want), 1e-5 * 12, f"{k} of {batch} transforms vs the oracle's fft0 (complex double)"
+
+    meta["parity"] = parity
     return step, batch * n, meta
 
 
@@ -136,10 +150,19 @@ def make_fir(torch, dev, ops, rank, mode):
         units = channels * (n - (ntaps - 1)) * ntaps
     else:
         meta = dict(metric="fir_overlap_save_throughput", unit="GSamples/s", dtype="f32", bound="hbm",
-                    alg_per_unit=8.0, alg_unit="bytes/sample (4 B read + 4 B write)", kernel="fir_overlap_save_kernel")
+                    alg_per_unit=8.0, alg_unit="bytes/sample (4 B read + 4 B write)",
+                    kernel="fir_os_wave_kernel<2> (+ fir_overlap_save_kernel<12> on the 2 x 1,024 edge block pairs, ~36 us)")
         units = channels * n
     meta["config"] = {"workload": f"C3: 511-tap windowed-sinc FIR ({mode}), 1,024 ch x 2^20 samples fp32 noise, per GPU",
                       "channels": channels, "n": n, "ntaps": ntaps, "sharding": "channels, no collective"}
+
+    def parity(orc):  # the first 2^16 samples of the last channel (a causal filter: a prefix is self-contained)
+        m = 1 << 16
+        want = orc.fir(x[-1, :m].cpu().numpy().astype(np.float64), taps)
+        tol = 1e-6 if mode.startswith("direct") else 1e-5 * 12
+        return _rel_l2(y[-1, :m].cpu().numpy(), want), tol, "2^16-sample prefix of one channel vs SincFilter::apply in double"
+
+    meta["parity"] = parity
     return step, units, meta
 
 
@@ -156,6 +179,13 @@ def make_mavg(torch, dev, ops, rank):
                 alg_unit="bytes/sample", kernel="moving_average_kernel",
                 config={"workload": "511-point centred moving average, 1,024 ch x 2^20 samples, per GPU",
                         "channels": channels, "n": n, "npoints": pts})
+
+    def parity(orc):  # a centred window: outputs up to m - pts/2 - 1 of a prefix of m samples are the full signal's
+        m = 1 << 16
+        want = orc.moving_average(x[-1, :m].cpu().numpy().astype(np.float64), pts)[: m - pts]
+        return _rel_l2(y[-1, : m - pts].cpu().numpy(), want), 1e-6, "2^16-sample prefix of one channel vs MovingAverageFilter in double"
+
+    meta["parity"] = parity
     return step, channels * n, meta
 
 
@@ -186,6 +216,14 @@ def make_iir(torch, dev, ops, rank, mode):
     meta = dict(metric=f"iir_{mode}_throughput", unit="GSamples/s", dtype="f32", bound="hbm", alg_per_unit=8.0,
                 alg_unit="bytes/sample (4 B read + 4 B write)", kernel=f"iir_{mode}_kernel",
                 config={"workload": wl, "channels": channels, "n": n, "poles": 4})
+
+    def parity(orc):  # zero initial state: a prefix is self-contained
+        m = min(n, 1 << 18)
+        want = orc.iir(x[-1:, :m].cpu().numpy().astype(np.float64), a, b)
+        return _rel_l2(y[-1:, :m].cpu().numpy(), want), 1e-4, f"{m}-sample prefix of one channel vs Coefficients<4> in double"
+
+    if not time_sharded:
+        meta["parity"] = parity
     return step, channels * n, meta
 
 
@@ -223,11 +261,24 @@ def make_swept(torch, dev, ops, rank, shared=False):
 
 def make_fft_dist(torch, dev, world, rank, exchange, serial=False):
     """C5: ONE transform of world * 2^27 points (2^30 on 8 GPUs), six-step with all-to-all over xGMI."""
-    from dsp_amd import dist_fft
+    import torch.distributed as dist
+
+    from dsp_amd import dist_fft, ops
     log2n = 27 + (world.bit_length() - 1)
     per_rank = (1 << log2n) // world
     g = torch.Generator(device=dev).manual_seed(2030 + rank)
     x = 0.01 * torch.view_as_complex(torch.randn(per_rank, 2, device=dev, generator=g))
+    stream = torch.cuda.current_stream(dev)
+
+    def timed(fn, reps=3):
+        fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(reps):
+            fn()
+        e1.record(stream)
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
 
     if exchange == "rccl":  # all of it inside the library: dsp_gpu_fft_dist with grouped ncclSend/ncclRecv
         comm = dist_fft.RcclCommunicator(rank, world)
@@ -236,10 +287,69 @@ def make_fft_dist(torch, dev, world, rank, exchange, serial=False):
 
         def step():
             plan.run(x, False, out=y, serial=serial)
+
+        def transform(t, lg):  # the same route at another size (parity check)
+            c = dist_fft.NativePlan(lg, rank, world, nccl_comm=comm.handle)
+            try:
+                return c.run(t, False, serial=serial)
+            finally:
+                torch.cuda.synchronize()
+                c.close()
     else:
 
         def step():  # the library's plan handle runs the local phases; torch.distributed (RCCL) the exchanges
             dist_fft.fft_dist(x, log2n, False)
+
+        def transform(t, lg):
+            return dist_fft.fft_dist(t, lg, False)
+
+    def report():
+        """Run BEFORE the timed region, on every rank: (1) parity of the distributed route at 2^24 points against the
+        single-GPU transform of the gathered input; (2) event-timed anatomy: local passes alone, each exchange alone,
+        the serial and the pipelined schedule, and the share of the exchange time the pipeline hides."""
+        lg = 24
+        n_loc = (1 << lg) // world
+        gg = torch.Generator(device=dev).manual_seed(77 + rank)
+        xl = torch.view_as_complex(torch.randn(n_loc, 2, device=dev, generator=gg))
+        got = transform(xl, lg)
+        if world > 1:
+            parts = [torch.empty_like(xl) for _ in range(world)]
+            dist.all_gather(parts, xl)
+            full = torch.cat(parts)
+        else:
+            full = xl
+        want = ops.fft0(full.reshape(1, -1), False).reshape(-1)[rank * n_loc:(rank + 1) * n_loc]
+        err = float((torch.linalg.vector_norm(got - want) / torch.linalg.vector_norm(want)).item())
+        rep = {"parity_2p24": {"rel_l2_vs_single_gpu": err, "tol": 2e-5 * lg, "ok": bool(err <= 2e-5 * lg),
+                               "what": f"2^24-point transform over {world} rank(s) against dsp_gpu_fft_batch of the gathered input"}}
+        # anatomy at the benchmark's size
+        phases = dist_fft.native_phases(log2n, rank, world, False)
+
+        def local_only():
+            t = x
+            for ph in phases:
+                t = ph(t)
+
+        rep["local_passes_ms"] = timed(local_only)
+        send = torch.view_as_real(x).contiguous()
+        recv = torch.empty_like(send)
+        if dist.is_initialized():
+            rep["exchange_ms"] = [timed(lambda: dist.all_to_all_single(recv, send)) for _ in range(3)]
+            rep["exchange_what"] = (f"one all_to_all_single of {send.numel() * 4 // max(world, 1)} B per peer, "
+                                    "event-timed alone, three times")
+        if exchange == "rccl":
+            rep["serial_ms"] = timed(lambda: plan.run(x, False, out=y, serial=True))
+            rep["pipelined_ms"] = timed(lambda: plan.run(x, False, out=y, serial=False))
+            ex = rep["serial_ms"] - rep["local_passes_ms"]
+            rep["exchange_in_serial_ms"] = ex
+            rep["overlap_fraction"] = (rep["serial_ms"] - rep["pipelined_ms"]) / ex if ex > 0 else None
+            rep["overlap_what"] = ("(serial - pipelined) / (serial - local passes alone): the share of the exchange time the "
+                                   "pipelined schedule hides; scripts/dist_overlap.py computes the same from a kernel trace")
+        else:
+            rep["overlap_fraction"] = 0.0
+            rep["overlap_what"] = "phases and all_to_all_single alternate on one stream: nothing overlaps by construction"
+        del send, recv
+        return rep
 
     meta = dict(metric="distributed_fft_throughput", unit="GSamples/s", dtype="f32", bound="hbm",
                 alg_per_unit=48.0, alg_unit="bytes/sample (3 local passes x 16 B; the exchanges ride xGMI)",
@@ -248,8 +358,14 @@ def make_fft_dist(torch, dev, world, rank, exchange, serial=False):
                         "log2n": log2n,
                         "exchange": (f"{plan.exchanges(serial=serial)} x grouped ncclSend/ncclRecv inside dsp_gpu_fft_dist"
                                      f" ({'serial' if serial or plan.exchanges() == 3 else 'pipelined'} schedule)")
-                        if exchange == "rccl" else "3 x all_to_all_single (RCCL)"})
+                        if exchange == "rccl" else "3 x all_to_all_single (RCCL)"},
+                dist_report=report)
     return step, per_rank, meta
+
+
+def _rel_l2(got, want):
+    got, want = np.asarray(got), np.asarray(want)
+    return float(np.linalg.norm(got.astype(want.dtype) - want) / max(float(np.linalg.norm(want)), 1e-300))
 
 
 def sinc_taps_host(cf, length):
@@ -371,7 +487,7 @@ def main():
         if use_dist:
             dist.barrier()
 
-    def measure(workload, steps, warmup):
+    def measure(workload, steps, warmup, want_parity=True):
         """Warm up, then time exactly `steps` passes of one workload between barriers; returns the rank-0 record parts."""
         if workload == "fft_dist":
             step, units, meta = make_fft_dist(torch, dev, world, rank, args.dist_exchange, args.dist_serial)
@@ -388,6 +504,11 @@ def main():
             step, units, meta = make_swept(torch, dev, ops, rank, shared=workload.endswith("shared"))
         else:
             step, units, meta = make_iir(torch, dev, ops, rank, "batch" if workload == "iir_batch" else "scan")
+        extra = {}
+        if "dist_report" in meta:  # self-verification of the multi-GPU route, before anything is timed
+            extra["dist"] = meta["dist_report"]()
+            if not extra["dist"]["parity_2p24"]["ok"]:
+                raise SystemExit(f"fft_dist parity failed on rank {rank}: {extra['dist']['parity_2p24']}")
         for _ in range(warmup):
             step()
         torch.cuda.synchronize()
@@ -406,8 +527,32 @@ def main():
         barrier()
         elapsed = time.perf_counter() - t0
         kernel_ms = e0.elapsed_time(e1) / steps
+        # per-step times: a second pass of the same K steps straight after, one event after every step (kept out of the
+        # timed region so that it stays exactly the K launches the contract names)
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+        marks[0].record(stream)
+        for i in range(steps):
+            step()
+            marks[i + 1].record(stream)
+        torch.cuda.synchronize()
+        per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps))
+        step_ms = {"mean": kernel_ms, "median": per_step[len(per_step) // 2] if len(per_step) % 2 else
+                   0.5 * (per_step[len(per_step) // 2 - 1] + per_step[len(per_step) // 2]), "min": per_step[0],
+                   "max": per_step[-1],
+                   "what": "mean: HIP events around the timed region / K; median, min, max: K more steps, an event after each"}
         elapsed = multigpu.max_over_ranks(elapsed, dev)
         all_units = multigpu.sum_over_ranks(float(units), dev)  # ranks may own unequal shares under strong scaling
+        if use_dist:  # what every rank processed per step (strong scaling: the shares; weak: N equal batches)
+            mine = torch.tensor([float(units)], dtype=torch.float64, device=dev)
+            shares = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(shares, mine)
+            extra["per_rank_units"] = [int(t.item()) for t in shares]
+        if want_parity and world == 1 and not args.no_cpu_baseline and "parity" in meta:
+            from oracle import load  # the checker: a slice of the buffers the timed steps just wrote, outside the timed region
+            err, tol, what = meta["parity"](load("oracle"))
+            extra["parity"] = {"rel_l2": err, "tol": tol, "ok": bool(err <= tol), "what": what}
+        meta.pop("parity", None)  # the closures hold the device buffers
+        meta.pop("dist_report", None)
         del step
         torch.cuda.empty_cache()
         value = all_units * steps / elapsed / 1e9
@@ -420,32 +565,60 @@ def main():
             achieved = units * meta["alg_per_unit"] / launch_s / 1e12
             roof = {"bound": "mfma", "achieved": achieved, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": achieved / FP32_PEAK_TFLOPS}
-        roof.update({"traffic": measured_traffic(workload), "kernel": meta["kernel"],
-                     "launch_ms": kernel_ms, "algorithmic": meta["alg_unit"]})
-        return {"metric": meta["metric"], "value": value, "unit": meta["unit"], "ms_per_step": elapsed / steps * 1e3,
-                "dtype": meta["dtype"], "config": meta["config"], "roofline": roof}
+        traffic = measured_traffic(workload)
+        roof.update({"traffic": traffic,
+                     "traffic_source": "profiles/traffic.json (rocprofv3 PMC passes committed with the tree, not this run)"
+                     if traffic is not None else None,
+                     "kernel": meta["kernel"], "launch_ms": kernel_ms, "algorithmic": meta["alg_unit"]})
+        rec = {"metric": meta["metric"], "value": value, "unit": meta["unit"], "ms_per_step": elapsed / steps * 1e3,
+               "dtype": meta["dtype"], "config": meta["config"], "roofline": roof, "step_ms": step_ms}
+        rec.update(extra)
+        return rec
+
+    # N > 1 (or the world-1 rehearsal): prove that RCCL really spans the ranks the launcher promised before timing anything
+    rccl_ranks = None
+    if use_dist:
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)
+        rccl_ranks = int(ones.item())
+        if rccl_ranks != args.gpus or dist.get_world_size() != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but RCCL sums {rccl_ranks} ranks (world size {dist.get_world_size()})")
+        if rank == 0:
+            print(f"[bench] rccl_ranks == {rccl_ranks} == --gpus {args.gpus}: ok", file=sys.stderr, flush=True)
 
     # BASELINE.json's metric also names the FIR (GMAC/s) and IIR rates: the default run times those workloads too, at
     # their full C3 / C4 sizes, with the same barriers and step count, and reports them beside the headline value.
-    # Order: the headline FFT is timed LAST (--headline-first restores the old order).  A memory-bound workload timed
-    # first in a fresh process sees the chip still ramping (its first ~40 launches run up to 8 % slow);
-    # the first one here is the MFMA-bound direct FIR, which does not care, and everything after it -- the headline
-    # included -- is timed at the sustained clocks a serving process runs at.
+    # Order: the headline FFT is timed FIRST (reported as `cold`: a memory-bound workload timed first in a fresh process
+    # sees the chip still ramping -- its first ~40 launches run up to 8 % slow) AND LAST (`value`: the
+    # sustained clocks a serving process runs at).  The first secondary workload is the MFMA-bound direct FIR, which
+    # does not care about the ramp.  --headline-first reports the cold measurement as `value` instead.
     secondary = []
-    main_rec = None
+    main_rec = cold_rec = None
     if args.workload == "fft" and not args.no_secondary:
-        if args.headline_first:
-            main_rec = measure(args.workload, args.steps, args.warmup)
+        cold_rec = measure(args.workload, args.steps, args.warmup, want_parity=False)
         for w in SECONDARY:
             secondary.append((w, measure(w, args.steps, args.warmup)))
-    if main_rec is None:
-        main_rec = measure(args.workload, args.steps, args.warmup)
+    main_rec = measure(args.workload, args.steps, args.warmup)
+    if cold_rec is not None and args.headline_first:
+        main_rec, cold_rec = dict(cold_rec, parity=main_rec.get("parity")), main_rec
 
     if rank == 0:
         line = {"metric": main_rec["metric"], "value": main_rec["value"], "unit": main_rec["unit"], "n_gpus": world,
                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": main_rec["ms_per_step"],
                 "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": main_rec["dtype"],
-                "data": "synthetic", "config": main_rec["config"], "roofline": main_rec["roofline"]}
+                "data": "synthetic", "config": main_rec["config"], "roofline": main_rec["roofline"],
+                "step_ms": main_rec["step_ms"]}
+        for k in ("parity", "dist", "per_rank_units"):
+            if main_rec.get(k) is not None:
+                line[k] = main_rec[k]
+        if rccl_ranks is not None:
+            line["rccl_ranks"] = rccl_ranks
+        if cold_rec is not None:
+            line["cold" if not args.headline_first else "sustained"] = {
+                "value": cold_rec["value"], "ms_per_step": cold_rec["ms_per_step"], "launch_ms": cold_rec["roofline"]["launch_ms"],
+                "frac": cold_rec["roofline"]["frac"], "step_ms": cold_rec["step_ms"],
+                "what": ("the same K steps measured first in the fresh process, before the secondary workloads"
+                         if not args.headline_first else "the same K steps measured last, after the secondary workloads")}
         cpu = world == 1 and not args.no_cpu_baseline and args.workload not in ("fft_32k", "fft_real_64k", "fft_f64")
         if cpu:
             line["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_seconds)
@@ -458,7 +631,9 @@ def main():
             for w, rec in secondary:
                 rec = dict(rec, workload=w, steps=args.steps, warmup=args.warmup)
                 if cpu:
-                    rec["cpu_baseline"] = cpu_baseline(w, min(args.cpu_seconds / 4, 3.0))
+                    rec["cpu_baseline"] = cpu_baseline(w, min(args.cpu_seconds / 4, 1.5))
+                    if args.cpu_threads > 1:
+                        rec["cpu_baseline_all_cores"] = cpu_baseline(w, min(args.cpu_seconds / 6, 1.0), args.cpu_threads)
                 line["secondary"].append(rec)
         print(json.dumps(line), flush=True)
     if use_dist:
