@@ -6,6 +6,7 @@
 // fail with DSP_GPU_EHIP.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <unordered_map>
@@ -61,8 +62,21 @@ struct TapLease {  // what a call gets: pointers by value, valid until release_t
     const float2 *d_spectrum = nullptr;
 };
 
-struct DeviceState {
+// The growing device workspaces, ONE SET PER (device, stream): two streams (or two host threads, each on its own
+// stream) never share scratch memory, so calls on different streams of one device may overlap.  A device keeps up to
+// kStreamSets sets; a further stream takes over the least recently used set together with its buffers after one
+// hipDeviceSynchronize (rare: more than kStreamSets distinct streams in rotation).
+constexpr int kStreamSets = 8;
+struct StreamSet {
+    hipStream_t stream = nullptr;
+    bool used = false;
+    unsigned long long stamp = 0;
     Buffer ws[WS_SLOTS];
+};
+
+struct DeviceState {
+    StreamSet sets[kStreamSets];
+    unsigned long long set_clock = 0;
     std::vector<TapSlot> taps;  // sized once (kTapCacheEntries): slots never move
     unsigned long long clock = 0;
 };
@@ -194,8 +208,8 @@ struct HostStage {  // mem == HOST helper: device mirrors of the caller's buffer
 };
 
 int stage_in(const void *host, size_t in_bytes, size_t out_bytes, hipStream_t s, HostStage *hs) {
-    if (int rc = workspace(WS_STAGE_IN, in_bytes, &hs->d_in)) return rc;
-    if (int rc = workspace(WS_STAGE_OUT, out_bytes, &hs->d_out)) return rc;
+    if (int rc = workspace(WS_STAGE_IN, in_bytes, &hs->d_in, s)) return rc;
+    if (int rc = workspace(WS_STAGE_OUT, out_bytes, &hs->d_out, s)) return rc;
     DSPGPU_HIP(hipMemcpyAsync(hs->d_in, host, in_bytes, hipMemcpyHostToDevice, s));
     return DSP_GPU_OK;
 }
@@ -219,11 +233,31 @@ int host_route(const void *in, size_t in_unit, size_t in_total, void *out, size_
 
 }  // namespace
 
-int workspace(WorkspaceSlot slot, size_t bytes, void **ptr) {
+int workspace(WorkspaceSlot slot, size_t bytes, void **ptr, hipStream_t s) {
     int dev = 0;
     if (int rc = current_device(&dev)) return rc;
+    // DSP_GPU_SHARED_WORKSPACES=1: one set per device whatever the stream, as until round 2 (what
+    // tests/test_streams_gpu.py guards against; kept to show that the test can fail)
+    static const bool shared = [] { const char *e = std::getenv("DSP_GPU_SHARED_WORKSPACES"); return e && e[0] == '1'; }();
+    if (shared) s = nullptr;
     std::lock_guard<std::mutex> lock(g_mutex);
-    Buffer &b = g_dev[dev].ws[slot];
+    DeviceState &st = g_dev[dev];
+    StreamSet *set = nullptr, *victim = nullptr;
+    for (StreamSet &c : st.sets) {
+        if (c.used && c.stream == s) {
+            set = &c;
+            break;
+        }
+        if (!victim || (!c.used && victim->used) || (c.used == victim->used && c.stamp < victim->stamp)) victim = &c;
+    }
+    if (!set) {
+        set = victim;
+        if (set->used) DSPGPU_HIP(hipDeviceSynchronize());  // the old stream's launches may still use these buffers
+        set->used = true;
+        set->stream = s;
+    }
+    set->stamp = ++st.set_clock;
+    Buffer &b = set->ws[slot];
     if (b.bytes < bytes) {
         if (b.ptr) {
             DSPGPU_HIP(hipDeviceSynchronize());  // earlier launches may still use the old buffer
@@ -265,7 +299,8 @@ void release_all_workspaces() {
             std::lock_guard<std::mutex> lock(g_mutex);
             DeviceState &st = g_dev[d];
             used = used || !st.taps.empty();
-            for (const Buffer &b : st.ws) used = used || b.ptr;
+            for (const StreamSet &c : st.sets)
+                for (const Buffer &b : c.ws) used = used || b.ptr;
         }
         if (!used) continue;
         if (hipSetDevice(d) != hipSuccess) continue;
@@ -274,9 +309,12 @@ void release_all_workspaces() {
         release_host_pipes(d);
         std::lock_guard<std::mutex> lock(g_mutex);
         DeviceState &st = g_dev[d];
-        for (Buffer &b : st.ws) {
-            if (b.ptr) (void)hipFree(b.ptr);
-            b = Buffer{};
+        for (StreamSet &c : st.sets) {
+            for (Buffer &b : c.ws) {
+                if (b.ptr) (void)hipFree(b.ptr);
+                b = Buffer{};
+            }
+            c = StreamSet{};
         }
         for (TapSlot &e : st.taps) {
             if (e.d_taps) (void)hipFree(e.d_taps);
@@ -467,7 +505,7 @@ static int convolve_impl(const char *who, const float *x, float *y, size_t chann
         dy = static_cast<float *>(hs.d_out);
         if (history && hist_bytes) {
             void *p = nullptr;
-            if (int rc = workspace(WS_STATE, hist_bytes, &p)) return rc;
+            if (int rc = workspace(WS_STATE, hist_bytes, &p, s)) return rc;
             dhist = static_cast<float *>(p);
             DSPGPU_HIP(hipMemcpyAsync(dhist, history, hist_bytes, hipMemcpyHostToDevice, s));
         }
@@ -484,7 +522,7 @@ static int convolve_impl(const char *who, const float *x, float *y, size_t chann
     if (rc) return rc;
     if (history && hist_bytes) {  // new history = last ntaps-1 samples of (old history ++ x), via a scratch copy
         void *p = nullptr;
-        if (int rc2 = workspace(WS_FIR_HIST, hist_bytes, &p)) return rc2;
+        if (int rc2 = workspace(WS_FIR_HIST, hist_bytes, &p, s)) return rc2;
         if (int rc2 = launch_fir_history(dx, n, old_hist, static_cast<float *>(p), channels, ntaps, s)) return rc2;
         DSPGPU_HIP(hipMemcpyAsync(dhist, p, hist_bytes, hipMemcpyDeviceToDevice, s));
         if (mem == DSP_GPU_MEM_HOST) DSPGPU_HIP(hipMemcpyAsync(history, dhist, hist_bytes, hipMemcpyDeviceToHost, s));
@@ -696,7 +734,7 @@ int dsp_gpu_iir_multi_ex(const void *xv, void *yv, int sample_type, size_t chann
         dx = hs.d_in;
         dy = hs.d_out;
         void *p = nullptr;
-        if (int rc = workspace(WS_SCRATCH_A, (2 * ab + 2 * channels) * sizeof(double), &p)) return rc;
+        if (int rc = workspace(WS_SCRATCH_A, (2 * ab + 2 * channels) * sizeof(double), &p, s)) return rc;
         double *dc = static_cast<double *>(p);
         DSPGPU_HIP(hipMemcpyAsync(dc, a, ab * sizeof(double), hipMemcpyHostToDevice, s));
         DSPGPU_HIP(hipMemcpyAsync(dc + ab, b, ab * sizeof(double), hipMemcpyHostToDevice, s));
@@ -711,7 +749,7 @@ int dsp_gpu_iir_multi_ex(const void *xv, void *yv, int sample_type, size_t chann
             pc.d0 = dc + 2 * ab + channels;
         }
         if (state) {
-            if (int rc = workspace(WS_STATE, state_bytes, &p)) return rc;
+            if (int rc = workspace(WS_STATE, state_bytes, &p, s)) return rc;
             dstate = static_cast<double *>(p);
             DSPGPU_HIP(hipMemcpyAsync(dstate, state, state_bytes, hipMemcpyHostToDevice, s));
         }
@@ -767,12 +805,12 @@ int dsp_gpu_biquad_swept(const float *x, const float *fc, float *y, size_t chann
     HostStage hs;
     if (int rc = stage_in(x, bytes, bytes, s, &hs)) return rc;
     void *p = nullptr;
-    if (int rc = workspace(WS_SCRATCH_A, fc_bytes, &p)) return rc;
+    if (int rc = workspace(WS_SCRATCH_A, fc_bytes, &p, s)) return rc;
     float *dfc = static_cast<float *>(p);
     DSPGPU_HIP(hipMemcpyAsync(dfc, fc, fc_bytes, hipMemcpyHostToDevice, s));
     double *dstate = nullptr;
     if (state) {
-        if (int rc = workspace(WS_STATE, state_bytes, &p)) return rc;
+        if (int rc = workspace(WS_STATE, state_bytes, &p, s)) return rc;
         dstate = static_cast<double *>(p);
         DSPGPU_HIP(hipMemcpyAsync(dstate, state, state_bytes, hipMemcpyHostToDevice, s));
     }

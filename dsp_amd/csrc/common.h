@@ -76,12 +76,13 @@ __device__ __forceinline__ size_t xcd_tile_of(unsigned block, size_t chunk) {
 }
 #endif
 
-// Device workspace owned by the library (one growing buffer per device and slot).
-// Slots keep independent users (host staging in/out, FFT scratch, ...) from aliasing.
+// Device workspace owned by the library: one growing buffer per (device, STREAM, slot) -- calls on different streams
+// never share scratch memory (capi.hip).  Slots keep independent users (host staging in/out, FFT scratch, ...) of one
+// call from aliasing.  `s` is the stream the caller launches on.
 enum WorkspaceSlot {
     WS_STAGE_IN = 0, WS_STAGE_OUT, WS_SCRATCH_A, WS_SCRATCH_B, WS_STATE, WS_STATE_SNAP, WS_IIR_TABLE, WS_FIR_HIST, WS_SLOTS
 };
-int workspace(WorkspaceSlot slot, size_t bytes, void **ptr);
+int workspace(WorkspaceSlot slot, size_t bytes, void **ptr, hipStream_t s);
 // Lets kernel `fn` use up to the CU's whole 160 KiB of dynamic LDS; issued once per kernel and device, not per launch.
 int allow_full_lds(const void *fn);
 void release_all_workspaces();

@@ -400,7 +400,7 @@ int launch_fft_batch_f64(const double *in_d, double *out_d, int log2n, size_t ba
     const int l1 = (log2n + 1) / 2, l2 = log2n - l1;
     const size_t n1 = static_cast<size_t>(1) << l1, n2 = static_cast<size_t>(1) << l2, n = n1 * n2;
     void *scratch_v = nullptr;
-    if (int rc = workspace(WS_SCRATCH_A, batch * n * sizeof(c64), &scratch_v)) return rc;
+    if (int rc = workspace(WS_SCRATCH_A, batch * n * sizeof(c64), &scratch_v, s)) return rc;
     c64 *scratch = static_cast<c64 *>(scratch_v);
     static const bool with_transposes = [] {  // DSP_GPU_F64_TRANSPOSES=1: the five-pass form below (A/B partner)
         const char *e = std::getenv("DSP_GPU_F64_TRANSPOSES");

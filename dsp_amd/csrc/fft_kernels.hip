@@ -807,7 +807,7 @@ int launch_large(const c32 *in, c32 *out, int log2n, size_t batch, int direction
     c32 *scratch = fixed_scratch;
     if (!scratch) {
         void *scratch_v = nullptr;
-        if (int rc = workspace(WS_SCRATCH_A, batch * n * sizeof(c32), &scratch_v)) return rc;
+        if (int rc = workspace(WS_SCRATCH_A, batch * n * sizeof(c32), &scratch_v, s)) return rc;
         scratch = static_cast<c32 *>(scratch_v);
     }
     // destination of pass i: the last one writes `out` and they alternate backwards; in place, the first pass
@@ -925,7 +925,7 @@ int launch_fft_columns(const float2 *in_f2, float2 *out_f2, int log2n, size_t co
         if (!fft_columns_tiled(log2n, cols)) {
             const size_t n = static_cast<size_t>(1) << log2n;
             void *tv = nullptr;
-            if (int rc = workspace(WS_SCRATCH_B, n * cols * sizeof(c32), &tv)) return rc;
+            if (int rc = workspace(WS_SCRATCH_B, n * cols * sizeof(c32), &tv, s)) return rc;
             float2 *t = static_cast<float2 *>(tv);
             if (int rc = launch_transpose_blocks(in_f2, t, 1, n, cols, s)) return rc;   // t[col][row]
             if (int rc = launch_fft_batch(t, t, log2n, cols, direction, s)) return rc;  // in place (scratch slot A above 2^14)
@@ -941,7 +941,7 @@ int launch_fft_columns(const float2 *in_f2, float2 *out_f2, int log2n, size_t co
     const int la = (log2n + 1) / 2, lb = log2n - la;
     const size_t na = static_cast<size_t>(1) << la, nb = static_cast<size_t>(1) << lb;
     void *scratch_v = nullptr;
-    if (int rc = workspace(WS_SCRATCH_B, (na * nb * cols) * sizeof(c32), &scratch_v)) return rc;
+    if (int rc = workspace(WS_SCRATCH_B, (na * nb * cols) * sizeof(c32), &scratch_v, s)) return rc;
     c32 *scratch = static_cast<c32 *>(scratch_v);
     const ColumnPlan p1{nb * cols, cols, na * cols, cols, log2n};
     if (int rc = launch_column(la, in, scratch, p1, 1, direction, s)) return rc;
@@ -997,7 +997,7 @@ int launch_fft_rows_exchange_chunk(const float2 *in_f2, float2 *out_f2, int log2
         return fail(DSP_GPU_EUNSUPPORTED, "fft_rows_exchange: shape not covered by the fused passes");
     const size_t n2 = static_cast<size_t>(1) << log2n2, na = q.na, nb = q.nb, C = q.C, Cc = C / chunks;
     void *scratch_v = nullptr;
-    if (int rc = workspace(WS_SCRATCH_A, rows * n2 * sizeof(c32), &scratch_v)) return rc;
+    if (int rc = workspace(WS_SCRATCH_A, rows * n2 * sizeof(c32), &scratch_v, s)) return rc;
     c32 *scratch = static_cast<c32 *>(scratch_v);
     int rlog = 0, klog = 0, olog = 0;
     while ((nb << rlog) < Cc) ++rlog;                        // n2a values per (sender, column chunk)

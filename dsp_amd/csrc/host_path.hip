@@ -222,7 +222,7 @@ int run_host_job(const HostJob &job, hipStream_t s) {
         // query.  Device layout [out | aux | in]: the way up carries [aux | in], the way back [out | aux].
         const size_t o_aux = up16(out_total), o_in = o_aux + up16(aux_bytes), all = o_in + up16(job.in_total);
         void *dv = nullptr;
-        if (int rc = workspace(WS_STAGE_OUT, std::max<size_t>(all, 16), &dv)) return rc;
+        if (int rc = workspace(WS_STAGE_OUT, std::max<size_t>(all, 16), &dv, s)) return rc;
         char *d = static_cast<char *>(dv);
         if (int rc = ring_reserve(p.ring_in, p.cap_in, all)) return rc;
         char *h = p.ring_in[0];
@@ -242,11 +242,11 @@ int run_host_job(const HostJob &job, hipStream_t s) {
     }
 
     void *din_v = nullptr, *dout_v = nullptr, *daux = nullptr;
-    if (int rc = workspace(WS_STAGE_IN, std::max<size_t>(job.in_total, 16), &din_v)) return rc;
-    if (int rc = workspace(WS_STAGE_OUT, std::max<size_t>(out_total, 16), &dout_v)) return rc;
+    if (int rc = workspace(WS_STAGE_IN, std::max<size_t>(job.in_total, 16), &din_v, s)) return rc;
+    if (int rc = workspace(WS_STAGE_OUT, std::max<size_t>(out_total, 16), &dout_v, s)) return rc;
     char *din = static_cast<char *>(din_v), *dout = static_cast<char *>(dout_v);
     if (aux_bytes) {
-        if (int rc = workspace(WS_STATE, aux_bytes, &daux)) return rc;
+        if (int rc = workspace(WS_STATE, aux_bytes, &daux, s)) return rc;
         DSPGPU_HIP(hipMemcpyAsync(daux, job.aux, aux_bytes, hipMemcpyHostToDevice, s));
     }
 

@@ -694,7 +694,7 @@ int scan_launch(const float *x, float *y, size_t channels, size_t n, const IirCo
                 d_table = t.ptr;
             } else {  // cache full: this call's own copy in the shared workspace slot
                 void *d_table_v = nullptr;
-                if (int rc = workspace(WS_IIR_TABLE, table.size() * sizeof(double), &d_table_v)) return rc;
+                if (int rc = workspace(WS_IIR_TABLE, table.size() * sizeof(double), &d_table_v, s)) return rc;
                 d_table = static_cast<double *>(d_table_v);
                 DSPGPU_HIP(hipMemcpyAsync(d_table, table.data(), table.size() * sizeof(double), hipMemcpyHostToDevice, s));
             }
@@ -722,8 +722,8 @@ int scan_launch(const float *x, float *y, size_t channels, size_t n, const IirCo
     }
     void *z_v = nullptr, *c_v = nullptr;
     const size_t carry_bytes = channels * ntiles * W * sizeof(double);
-    if (int rc = workspace(WS_SCRATCH_A, carry_bytes, &z_v)) return rc;
-    if (int rc = workspace(WS_SCRATCH_B, carry_bytes, &c_v)) return rc;
+    if (int rc = workspace(WS_SCRATCH_A, carry_bytes, &z_v, s)) return rc;
+    if (int rc = workspace(WS_SCRATCH_B, carry_bytes, &c_v, s)) return rc;
     double *tz = static_cast<double *>(z_v), *tc = static_cast<double *>(c_v);
     hipLaunchKernelGGL((iir_scan_kernel<P, SCAN_REDUCE, ALIGNED, WIDE>), grid, dim3(kSt), 0, s, x, y, n, co, d_table,
                        state_in, nullptr, tz, nullptr, ntiles, 0, levels, d_table + 18 * ms, 0);
@@ -845,7 +845,7 @@ int scan_dispatch(const float *x, float *y, size_t channels, size_t n, const Iir
     if (state) {
         void *snap = nullptr;
         const size_t sb = channels * 2 * P * sizeof(double);
-        if (int rc = workspace(WS_STATE_SNAP, sb, &snap)) return rc;
+        if (int rc = workspace(WS_STATE_SNAP, sb, &snap, s)) return rc;
         DSPGPU_HIP(hipMemcpyAsync(snap, state, sb, hipMemcpyDeviceToDevice, s));
         state_in = static_cast<const double *>(snap);
     }

@@ -20,17 +20,16 @@
  *     last failure on the calling thread.
  *   - the caller owns every buffer it passes.  The library owns per-device workspaces
  *     and cached tap uploads, released by dsp_gpu_shutdown().
- *   - intended multi-GPU use is one host thread (or process) per device with that device made
- *     current (hipSetDevice) before the call.  Thread-safe in the sense that the library's own tables
- *     (tap cache, IIR plans) are locked and handed out pinned; but the per-device WORKSPACES are shared,
- *     not keyed per stream, so calls that use one must not overlap on one device (from two threads or
- *     two streams): every DSP_GPU_MEM_HOST call (staging), FFTs above 2^15 points, dsp_gpu_fft_columns,
- *     dsp_gpu_fft_rows_exchange, dsp_gpu_convolve_stream (history scratch), dsp_gpu_iir with `state` or in
- *     a SCAN form that carries tile states, dsp_gpu_iir_multi from host memory, and
- *     dsp_gpu_fft_batch_noalloc (its fixed array).  Calls that touch no workspace -- device-pointer FFTs up
- *     to 2^15 points, dsp_gpu_convolve, dsp_gpu_moving_average, dsp_gpu_iir BATCH without state,
- *     dsp_gpu_biquad_swept -- may run
- *     concurrently on different streams.
+ *   - Threads and streams.  Intended multi-GPU use is one host thread (or process) per device with that device
+ *     made current (hipSetDevice) before the call.  The library's tables (tap cache, IIR plans) are locked and
+ *     handed out pinned, and its growing device workspaces (the ping-pong slab of FFTs above 2^15 points, IIR
+ *     tile carries and state snapshots, FIR history scratch, host staging) are kept PER (device, stream): calls
+ *     on different streams of one device -- from one host thread or several -- never share scratch memory and may
+ *     overlap freely (tests/test_streams_gpu.py).  What remains single-file: (i) calls that share ONE stream must
+ *     come from one host thread at a time (the usual rule for a stream); (ii) DSP_GPU_MEM_HOST calls on one device
+ *     serialise inside the library (one staging pipeline per device); (iii) dsp_gpu_fft_batch_noalloc's fixed
+ *     array is one per device: calls to it that overlap on one GPU race.  A device keeps workspace sets for 8
+ *     streams; a ninth takes over the least recently used set after one hipDeviceSynchronize.
  */
 #ifndef DSP_GPU_H
 #define DSP_GPU_H
