@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <unordered_map>
 #include <vector>
@@ -63,20 +64,25 @@ struct TapLease {  // what a call gets: pointers by value, valid until release_t
 };
 
 // The growing device workspaces, ONE SET PER (device, stream): two streams (or two host threads, each on its own
-// stream) never share scratch memory, so calls on different streams of one device may overlap.  A device keeps up to
-// kStreamSets sets; a further stream takes over the least recently used set together with its buffers after one
-// hipDeviceSynchronize (rare: more than kStreamSets distinct streams in rotation).
-constexpr int kStreamSets = 8;
+// stream) never share scratch memory, so calls on different streams of one device may overlap.  A device keeps about
+// kStreamSets sets; a further stream takes over the least recently used UNPINNED set together with its buffers after one
+// hipDeviceSynchronize (rare: more than kStreamSets distinct streams in rotation).  A set is pinned by the host thread
+// that last asked for it (a call's workspace() requests all name the same device and stream) until that thread asks for
+// another set or exits: a call that is still running on the host -- a DSP_GPU_MEM_HOST call pipelining its chunks --
+// never has its buffers taken from under it.  When every set is pinned the table grows instead.
+constexpr size_t kStreamSets = 8;
 struct StreamSet {
     hipStream_t stream = nullptr;
     bool used = false;
+    int pins = 0;
     unsigned long long stamp = 0;
     Buffer ws[WS_SLOTS];
 };
 
 struct DeviceState {
-    StreamSet sets[kStreamSets];
+    std::vector<std::unique_ptr<StreamSet>> sets;  // the sets never move (threads hold pointers to the one they pin)
     unsigned long long set_clock = 0;
+    unsigned long long epoch = 0;  // bumped by dsp_gpu_shutdown: pins taken before it name sets that no longer exist
     std::vector<TapSlot> taps;  // sized once (kTapCacheEntries): slots never move
     unsigned long long clock = 0;
 };
@@ -233,6 +239,24 @@ int host_route(const void *in, size_t in_unit, size_t in_total, void *out, size_
 
 }  // namespace
 
+namespace {
+struct ThreadPin {  // the set this host thread pins (at most one), released when the thread moves on or exits
+    StreamSet *set = nullptr;
+    int dev = -1;
+    unsigned long long epoch = 0;
+    void drop_locked() {
+        if (set && g_dev[dev].epoch == epoch) --set->pins;
+        set = nullptr;
+    }
+    ~ThreadPin() {
+        if (!set) return;
+        std::lock_guard<std::mutex> lock(g_mutex);
+        drop_locked();
+    }
+};
+thread_local ThreadPin t_pin;
+}  // namespace
+
 int workspace(WorkspaceSlot slot, size_t bytes, void **ptr, hipStream_t s) {
     int dev = 0;
     if (int rc = current_device(&dev)) return rc;
@@ -243,18 +267,33 @@ int workspace(WorkspaceSlot slot, size_t bytes, void **ptr, hipStream_t s) {
     std::lock_guard<std::mutex> lock(g_mutex);
     DeviceState &st = g_dev[dev];
     StreamSet *set = nullptr, *victim = nullptr;
-    for (StreamSet &c : st.sets) {
+    for (auto &up : st.sets) {
+        StreamSet &c = *up;
         if (c.used && c.stream == s) {
             set = &c;
             break;
         }
+        const bool mine = t_pin.set == &c && t_pin.dev == dev && t_pin.epoch == st.epoch && c.pins == 1;
+        if (c.pins != 0 && !mine) continue;  // in use by a call of another thread
         if (!victim || (!c.used && victim->used) || (c.used == victim->used && c.stamp < victim->stamp)) victim = &c;
     }
     if (!set) {
-        set = victim;
-        if (set->used) DSPGPU_HIP(hipDeviceSynchronize());  // the old stream's launches may still use these buffers
+        if (st.sets.size() < kStreamSets || !victim) {  // room left, or every set is pinned: a new one
+            st.sets.push_back(std::make_unique<StreamSet>());
+            set = st.sets.back().get();
+        } else {
+            set = victim;
+            if (set->used) DSPGPU_HIP(hipDeviceSynchronize());  // the old stream's launches may still use these buffers
+        }
         set->used = true;
         set->stream = s;
+    }
+    if (t_pin.set != set || t_pin.dev != dev || t_pin.epoch != st.epoch) {
+        t_pin.drop_locked();
+        t_pin.set = set;
+        t_pin.dev = dev;
+        t_pin.epoch = st.epoch;
+        ++set->pins;
     }
     set->stamp = ++st.set_clock;
     Buffer &b = set->ws[slot];
@@ -299,8 +338,7 @@ void release_all_workspaces() {
             std::lock_guard<std::mutex> lock(g_mutex);
             DeviceState &st = g_dev[d];
             used = used || !st.taps.empty();
-            for (const StreamSet &c : st.sets)
-                for (const Buffer &b : c.ws) used = used || b.ptr;
+            used = used || !st.sets.empty();
         }
         if (!used) continue;
         if (hipSetDevice(d) != hipSuccess) continue;
@@ -309,13 +347,11 @@ void release_all_workspaces() {
         release_host_pipes(d);
         std::lock_guard<std::mutex> lock(g_mutex);
         DeviceState &st = g_dev[d];
-        for (StreamSet &c : st.sets) {
-            for (Buffer &b : c.ws) {
+        for (auto &c : st.sets)
+            for (Buffer &b : c->ws)
                 if (b.ptr) (void)hipFree(b.ptr);
-                b = Buffer{};
-            }
-            c = StreamSet{};
-        }
+        st.sets.clear();
+        ++st.epoch;  // threads that still pin one of those sets must not touch it
         for (TapSlot &e : st.taps) {
             if (e.d_taps) (void)hipFree(e.d_taps);
             for (float2 *sp : e.d_spectrum)

@@ -10,7 +10,6 @@
 // one page-locked bounce each way.  Device side: the library's two staging workspaces hold the whole batch, so kernels
 // see the same contiguous arrays as on the device-pointer route.  No arithmetic happens on the host.
 #include <algorithm>
-#include <atomic>
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
@@ -61,6 +60,7 @@ public:
                 if (tasks[i].bytes) std::memcpy(tasks[i].dst, tasks[i].src, tasks[i].bytes);
             return;
         }
+        unsigned long long gen;
         {
             std::lock_guard<std::mutex> lock(m_);
             pieces_.clear();
@@ -68,12 +68,12 @@ public:
             for (int i = 0; i < ntasks; ++i)
                 for (size_t off = 0; off < tasks[i].bytes; off += piece)
                     pieces_.push_back(CopyTask{tasks[i].dst + off, tasks[i].src + off, std::min(piece, tasks[i].bytes - off)});
-            next_.store(0);
+            next_ = 0;
             left_ = pieces_.size();
-            ++generation_;
+            gen = ++generation_;
         }
         cv_.notify_all();
-        work();  // the caller copies too
+        work(gen);  // the caller copies too
         std::unique_lock<std::mutex> lock(m_);
         done_cv_.wait(lock, [&] { return left_ == 0; });
     }
@@ -94,11 +94,19 @@ private:
         cv_.notify_all();
         for (std::thread &t : workers_) t.join();
     }
-    void work() {
+    // Claims pieces of generation `gen` until none is left.  The piece list is only ever read under m_ and only for the
+    // generation the thread was woken for: a worker that is late (run() returns as soon as the LAST piece is copied, not
+    // when every worker has noticed) finds the generation changed and leaves the next call's list alone.  Pieces are
+    // >= 1 MiB, so the lock per claim costs nothing.
+    void work(unsigned long long gen) {
         for (;;) {
-            const size_t i = next_.fetch_add(1);
-            if (i >= pieces_.size()) return;
-            std::memcpy(pieces_[i].dst, pieces_[i].src, pieces_[i].bytes);
+            CopyTask t;
+            {
+                std::lock_guard<std::mutex> lock(m_);
+                if (gen != generation_ || next_ >= pieces_.size()) return;
+                t = pieces_[next_++];
+            }
+            std::memcpy(t.dst, t.src, t.bytes);
             std::lock_guard<std::mutex> lock(m_);
             if (--left_ == 0) done_cv_.notify_all();
         }
@@ -112,14 +120,14 @@ private:
                 if (stop_) return;
                 seen = generation_;
             }
-            work();
+            work(seen);
         }
     }
     std::vector<std::thread> workers_;
     std::mutex m_, call_mutex_;
     std::condition_variable cv_, done_cv_;
     std::vector<CopyTask> pieces_;
-    std::atomic<size_t> next_{0};
+    size_t next_ = 0;
     size_t left_ = 0;
     unsigned long long generation_ = 0;
     bool stop_ = false;

@@ -1,0 +1,202 @@
+// hammer.cpp -- the library's own host code (capi.hip, host_path.hip) under AddressSanitizer / UBSan / ThreadSanitizer on
+// a machine with no GPU (tests/host_sanitize/Makefile, driven by tests/test_host_sanitizers.py).
+//
+// HIP is the host-only stand-in of hip/hip_runtime.h, the kernels are stub_launchers.cpp, where an operation whose
+// input and output have the same size COPIES input to output.  So besides what the sanitizers watch, every call here
+// checks that what came back is what went in: the staging pipeline's chunk offsets, ring slots and copy threads move
+// every byte to the right place.
+//   1. tap cache: 300 tap sets (> its 256 slots: LRU take-overs) from 4 threads on 4 streams, direct and overlap-save,
+//      with re-use of recent sets (hits) and spectrum builds
+//   2. host route: 8 threads, batches of 16-48 MiB through the ring slots and the copy pool, on 3 "devices" (two threads
+//      share one), pageable and page-locked caller memory, in == out, partially overlapping buffers, real-input FFT
+//      (in_unit != out_unit), IIR with state as the auxiliary block
+//   3. per-stream workspace sets: 12 streams in rotation (> 8 sets: take-overs) through streamed convolution with
+//      history, per-channel-coefficient IIR and the swept band-pass from host memory
+//   4. the veneer (include/dsp_mi355x/dsp.hpp) on SampleBuffer<float> and <double>
+//   5. dsp_gpu_shutdown, then everything again once (tables rebuilt after a shutdown), shutdown: LeakSanitizer sees
+//      what the library forgot to free
+#include <dsp_mi355x/dsp.hpp>
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cstdio>
+#include <cstring>
+#include <cstdlib>
+#include <thread>
+#include <vector>
+
+#include "../../include/dsp_gpu.h"
+
+namespace {
+std::atomic<int> g_fail{0};
+#define EXPECT(cond, ...)                                        \
+    do {                                                         \
+        if (!(cond)) {                                           \
+            std::fprintf(stderr, "FAILED %s:%d: ", __FILE__, __LINE__); \
+            std::fprintf(stderr, __VA_ARGS__);                   \
+            std::fprintf(stderr, " [%s]\n", dsp_gpu_last_error_string()); \
+            ++g_fail;                                            \
+        }                                                        \
+    } while (0)
+
+int g_rounds = 3;  // argv[1]: host-route rounds per thread (ThreadSanitizer runs take one)
+
+std::vector<float> noise(size_t n, unsigned seed) {  // cheap, distinct per seed: the checks compare bytes, not statistics
+    std::vector<float> v(n);
+    unsigned long long st = 88172645463325252ull ^ (static_cast<unsigned long long>(seed) * 0x9E3779B97F4A7C15ull);
+    for (float &x : v) {
+        st ^= st << 13; st ^= st >> 7; st ^= st << 17;
+        x = static_cast<float>(static_cast<int>(st >> 40) & 0xFFFF) * (1.0f / 65536.0f) - 0.5f;
+    }
+    return v;
+}
+
+void tap_cache(int thread) {
+    hipSetDevice(0);
+    hipStream_t s;
+    hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+    const size_t channels = 3, n = 6000;
+    const std::vector<float> x = noise(channels * n, 100 + thread);
+    std::vector<float> y(x.size());
+    for (int k = 0; k < 75; ++k) {
+        const int set = thread * 75 + k;
+        const int ntaps = 33 + 2 * (set % 120);  // 33 .. 271 taps
+        const std::vector<float> taps = noise(ntaps, 7000 + set);
+        for (int mode : {DSP_GPU_CONV_DIRECT, DSP_GPU_CONV_OVERLAP_SAVE}) {
+            std::fill(y.begin(), y.end(), -3.f);
+            const int rc = dsp_gpu_convolve(x.data(), y.data(), channels, n, taps.data(), ntaps, mode, DSP_GPU_MEM_DEVICE, s);
+            EXPECT(rc == 0, "convolve set %d mode %d rc %d", set, mode, rc);
+        }
+        if (k >= 3) {  // a recent set again: a hit, possibly on a slot another thread is about to take over
+            const int old = thread * 75 + k - 3, nt = 33 + 2 * (old % 120);
+            const std::vector<float> taps2 = noise(nt, 7000 + old);
+            EXPECT(dsp_gpu_convolve(x.data(), y.data(), channels, n, taps2.data(), nt, DSP_GPU_CONV_AUTO, DSP_GPU_MEM_DEVICE, s) == 0, "re-use");
+        }
+    }
+    hipStreamDestroy(s);
+}
+
+void host_route(int thread) {
+    hipSetDevice(thread % 3);
+    for (int round = 0; round < g_rounds; ++round) {
+        const size_t batch = 512 + 256 * ((thread + round) % 5), n = 4096;  // 16 .. 48 MiB of complex fp32
+        std::vector<float> in = noise(batch * n * 2, 900 + 10 * thread + round), out(in.size(), -1.f);
+        EXPECT(dsp_gpu_fft_batch(in.data(), out.data(), 12, batch, DSP_GPU_FORWARD, DSP_GPU_MEM_HOST, nullptr) == 0, "fft host");
+        EXPECT(std::memcmp(in.data(), out.data(), in.size() * 4) == 0, "fft host: bytes moved wrongly (thread %d round %d)", thread, round);
+        // in place
+        std::vector<float> io = in;
+        EXPECT(dsp_gpu_fft_batch(io.data(), io.data(), 12, batch, DSP_GPU_FORWARD, DSP_GPU_MEM_HOST, nullptr) == 0, "fft in place");
+        EXPECT(io == in, "fft in place: bytes moved wrongly");
+        // partially overlapping caller buffers: out starts one transform into in
+        std::vector<float> both(in.size() + 2 * n);
+        std::memcpy(both.data(), in.data(), in.size() * 4);
+        EXPECT(dsp_gpu_fft_batch(both.data(), both.data() + 2 * n, 12, batch, DSP_GPU_FORWARD, DSP_GPU_MEM_HOST, nullptr) == 0, "fft overlap");
+        EXPECT(std::memcmp(both.data() + 2 * n, in.data(), in.size() * 4) == 0, "fft overlapping buffers: output corrupted");
+        // page-locked caller memory skips the ring
+        void *pin_v = nullptr, *pout_v = nullptr;
+        hipHostMalloc(&pin_v, in.size() * 4, hipHostMallocDefault);
+        hipHostMalloc(&pout_v, in.size() * 4, hipHostMallocDefault);
+        std::memcpy(pin_v, in.data(), in.size() * 4);
+        EXPECT(dsp_gpu_fft_batch(pin_v, pout_v, 12, batch, DSP_GPU_FORWARD, DSP_GPU_MEM_HOST, nullptr) == 0, "fft pinned");
+        EXPECT(std::memcmp(pout_v, in.data(), in.size() * 4) == 0, "fft pinned: bytes moved wrongly");
+        hipHostFree(pin_v);
+        hipHostFree(pout_v);
+        // real-input wrapper: rows of 3000 samples padded to 4096 bins (in_unit != out_unit), last row short of its stride
+        const size_t rows = 600, n_in = 3000;
+        std::vector<float> td = noise(rows * n_in, 5 + thread);
+        std::vector<float> spec(rows * 4096 * 2, 0.f);
+        EXPECT(dsp_gpu_fft_real_batch(td.data(), n_in, n_in, spec.data(), 4096, rows, DSP_GPU_FORWARD, 0, DSP_GPU_MEM_HOST, nullptr) == 0, "fft real");
+        // FIR / moving average / IIR with state through the same route
+        const size_t channels = 40 + thread, len = 1 << 17;
+        std::vector<float> x = noise(channels * len, 77 + thread), y(x.size(), -2.f);
+        const std::vector<float> taps = noise(127, 4242);
+        EXPECT(dsp_gpu_convolve(x.data(), y.data(), channels, len, taps.data(), 127, DSP_GPU_CONV_AUTO, DSP_GPU_MEM_HOST, nullptr) == 0, "convolve host");
+        EXPECT(x == y, "convolve host: bytes moved wrongly");
+        std::fill(y.begin(), y.end(), -2.f);
+        EXPECT(dsp_gpu_moving_average(x.data(), y.data(), channels, len, 51, DSP_GPU_MEM_HOST, nullptr) == 0, "mavg host");
+        EXPECT(x == y, "mavg host: bytes moved wrongly");
+        const double a[5] = {0.1, 0.2, 0.3, 0.2, 0.1}, b[5] = {0, 0.5, -0.2, 0.05, -0.01};
+        std::vector<double> state(channels * 8, 0.25);
+        std::fill(y.begin(), y.end(), -2.f);
+        EXPECT(dsp_gpu_iir(x.data(), y.data(), channels, len, a, b, 4, 1.0, 0.0, state.data(), DSP_GPU_IIR_BATCH, DSP_GPU_MEM_HOST, nullptr) == 0, "iir host");
+        EXPECT(x == y, "iir host: bytes moved wrongly");
+        // small call: the single-bounce route
+        std::vector<float> sx = noise(2048, 3), sy(2048);
+        EXPECT(dsp_gpu_fft_batch(sx.data(), sy.data(), 10, 1, DSP_GPU_INVERSE, DSP_GPU_MEM_HOST, nullptr) == 0, "small fft");
+        EXPECT(sx == sy, "small fft: bytes moved wrongly");
+    }
+}
+
+void stream_sets(int thread) {
+    hipSetDevice(1);
+    std::vector<hipStream_t> streams(6);
+    for (hipStream_t &s : streams) hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+    const size_t channels = 5, n = 2048;
+    const int ntaps = 201;
+    const std::vector<float> taps = noise(ntaps, 11);
+    for (int round = 0; round < 20; ++round) {
+        hipStream_t s = streams[(round + thread) % streams.size()];
+        std::vector<float> x = noise(channels * n, round), y(x.size());
+        std::vector<float> hist(channels * (ntaps - 1), 0.f);
+        for (int mem : {DSP_GPU_MEM_HOST, DSP_GPU_MEM_DEVICE})
+            for (int mode : {DSP_GPU_CONV_DIRECT, DSP_GPU_CONV_OVERLAP_SAVE})
+                EXPECT(dsp_gpu_convolve_stream(x.data(), y.data(), channels, n, taps.data(), ntaps, hist.data(),
+                                               static_cast<unsigned long long>(round) * n, mode, mem, s) == 0, "convolve_stream");
+        std::vector<double> a(channels * 5, 0.1), b(channels * 5, 0.01), c0(channels, 1.0), d0(channels, 0.0), st(channels * 8, 0.0);
+        EXPECT(dsp_gpu_iir_multi(x.data(), y.data(), channels, n, a.data(), b.data(), 4, c0.data(), d0.data(), st.data(),
+                                 DSP_GPU_MEM_HOST, s) == 0, "iir_multi");
+        std::vector<float> fc(n, 0.05f);
+        std::vector<double> bq(channels * 4, 0.0);
+        EXPECT(dsp_gpu_biquad_swept(x.data(), fc.data(), y.data(), channels, n, 0, 0, 0.01, bq.data(), DSP_GPU_MEM_HOST, s) == 0, "swept");
+    }
+    for (hipStream_t s : streams) hipStreamDestroy(s);
+}
+
+void veneer() {
+    hipSetDevice(2);
+    dsp::SampleBuffer<float> xf(5000);
+    dsp::SampleBuffer<double> xd(5000);
+    for (size_t i = 0; i < 5000; ++i) xf[i] = static_cast<float>(i % 17), xd[i] = static_cast<double>(i % 13);
+    dsp::filter::SincFilter<> sinc{0.1, 101};
+    auto yf = sinc.apply(xf);
+    auto yd = sinc.apply(xd);
+    dsp::filter::MovingAverageFilter ma{11};
+    auto mf = ma(xf);
+    auto md = ma(xd);
+    auto lp = dsp::recursive::lowPassFilter<4>(0.1);
+    auto zf = lp(xf);
+    auto lp2 = dsp::recursive::lowPassFilter<4>(0.1);
+    auto zd = lp2(xd);
+    auto bq = dsp::recursive::bandPassFilter(0.1, 0.01);
+    auto wf = bq(xf);
+    std::vector<std::complex<double>> spec(8192);
+    dsp::fft(xd.begin(), xd.end(), spec.begin(), 8192);
+    EXPECT(yf.size() == 5000 && yd.size() == 5000 && mf.size() == 5000 && md.size() == 5000 && zf.size() == 5000 &&
+               zd.size() == 5000 && wf.size() == 5000, "veneer sizes");
+}
+
+void everything() {
+    std::vector<std::thread> ts;
+    for (int t = 0; t < 4; ++t) ts.emplace_back(tap_cache, t);
+    for (int t = 0; t < 8; ++t) ts.emplace_back(host_route, t);
+    for (int t = 0; t < 2; ++t) ts.emplace_back(stream_sets, t);
+    ts.emplace_back(veneer);
+    for (std::thread &t : ts) t.join();
+}
+}  // namespace
+
+int main(int argc, char **argv) {
+    if (argc > 1) g_rounds = std::max(1, std::atoi(argv[1]));
+    everything();
+    EXPECT(dsp_gpu_shutdown() == 0, "shutdown");
+    everything();  // tables and pipelines come back after a shutdown
+    EXPECT(dsp_gpu_shutdown() == 0, "shutdown");
+    if (g_fail) {
+        std::fprintf(stderr, "%d check(s) failed\n", g_fail.load());
+        return 1;
+    }
+    std::puts("host hammer ok");
+    return 0;
+}
