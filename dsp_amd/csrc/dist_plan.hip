@@ -148,8 +148,14 @@ int pipeline_state(dsp_gpu_fft_dist_plan *p) {
         p->slots = static_cast<float2 *>(v);
     }
     if (!p->comm_stream) DSPGPU_HIP(hipStreamCreateWithFlags(&p->comm_stream, hipStreamNonBlocking));
+    const int n = 7 * K;
+    if (p->events && p->nevents < n) {  // an earlier call failed part-way: start over rather than record null events
+        for (int i = 0; i < p->nevents; ++i) (void)hipEventDestroy(p->events[i]);
+        delete[] p->events;
+        p->events = nullptr;
+        p->nevents = 0;
+    }
     if (!p->events) {
-        const int n = 7 * K;
         p->events = new (std::nothrow) hipEvent_t[n]();
         if (!p->events) return fail(DSP_GPU_ENOMEM, "dsp_gpu_fft_dist: out of host memory");
         for (p->nevents = 0; p->nevents < n; ++p->nevents)

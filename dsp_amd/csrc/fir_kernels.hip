@@ -694,6 +694,114 @@ __global__ __launch_bounds__(kOsWaveThreads) void fir_os_wave_kernel(
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no prefetch is pending here; belt and braces
 }
 
+// Round 3: the same work with TWO waves per SIMD and no hand-scheduled prefetch.  The transform's 64 x 64 transpose in its
+// QUAD form (fft_wave_core.h: v_permlane32_swap trades the off-diagonal blocks, two 32 x 33 images) needs 16.9 KB per
+// wave instead of 33 KB, so a CU holds the images of eight waves; with <= 256 registers per wave two of them share a
+// SIMD and cover each other's loads, LDS phases and issue bubbles -- plain HIP, scheduled by the compiler, none of the
+// AGPR / vmcnt bookkeeping above.  A wave walks a RUN of consecutive block pairs of the flattened (channel, block) list
+// and keeps the 256 * I0 samples that the next pair's first block shares with this pair's second block in registers, so
+// inside a run every input sample is read once (read amplification 4096 / hop only at the start of a run).
+// Same pairs as fir_os_wave_kernel (plain ones; the edge pairs go to fir_overlap_save_kernel), same arithmetic per pair:
+// the two kernels give identical bits.
+constexpr int kOsWave2Waves = 8;
+constexpr int kOsWave2Threads = 64 * kOsWave2Waves;
+constexpr size_t kOsWave2LdsBytes = kOsWaveHalfPad * sizeof(c32) + kOsWave2Waves * kWaveLdsQuadBytes;  // 151,616 B
+
+template <int I0>
+__global__ __launch_bounds__(kOsWave2Threads) void fir_os_wave2_kernel(
+    const float *__restrict__ x, float *__restrict__ y, size_t n, const c32 *__restrict__ hspec, unsigned blocks_per_channel,
+    size_t total_blocks, size_t tiles, unsigned run_len, size_t runs_per_xcd) {
+    constexpr int T = 64, P = kWavePoints;
+    constexpr long long L = kWaveN - 256 * I0;
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) unsigned char os_wave_lds[];
+    c32 *hs = reinterpret_cast<c32 *>(os_wave_lds);
+    const int lane = static_cast<int>(threadIdx.x) & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
+    float *img = reinterpret_cast<float *>(os_wave_lds + kOsWaveHalfPad * sizeof(c32) + wave * kWaveLdsQuadBytes);
+    constexpr float scale = 1.0f / kWaveN;  // the 1/N of the inverse transform rides the spectrum
+    for (int i = threadIdx.x; i < kOsWaveHalf; i += kOsWave2Threads) {
+        const c32 h = hspec[i];
+        hs[i] = mk(h.x * scale, h.y * scale);
+    }
+    __syncthreads();  // the only workgroup barrier
+    const c32 *hlo = hs + lane;                  // H[lane + 64 m],         m < 32
+    const c32 *hhi = hs + (kWaveN / 2 - lane);   // H[4096 - (lane + 64 m)], m >= 32:  hhi[-64 (m - 32)]
+    const long long nn = static_cast<long long>(n);
+    // each XCD works through one contiguous range of runs (workgroups b and b + 8 share an XCD)
+    const size_t run = (blockIdx.x & 7u) * runs_per_xcd + static_cast<size_t>(blockIdx.x >> 3) * kOsWave2Waves + wave;
+    const size_t tile0 = run * run_len;
+    if ((static_cast<size_t>(blockIdx.x >> 3) * kOsWave2Waves + wave) >= runs_per_xcd || tile0 >= tiles) return;
+    // (channel, block) of the first block of the pair, stepped by two blocks per pair
+    size_t ch = (2 * tile0) / blocks_per_channel;
+    unsigned blk = static_cast<unsigned>((2 * tile0) % blocks_per_channel);
+    float keep[4 * I0];  // rows 64 - 4 I0 .. 63 of the last pair's second block = rows 0 .. 4 I0 - 1 of the next pair's first
+    bool have_keep = false;
+#pragma unroll
+    for (int m = 0; m < 4 * I0; ++m) keep[m] = 0.0f;
+    for (unsigned pp = 0; pp < run_len; ++pp) {
+        const size_t tile = tile0 + pp;
+        if (tile >= tiles) break;
+        const size_t ch_a = ch;
+        const unsigned blk_a = blk;
+        const bool wrap = blk_a + 1 == blocks_per_channel;
+        const unsigned blk_b = wrap ? 0u : blk_a + 1;
+        blk += 2;
+        if (blk >= blocks_per_channel) blk -= blocks_per_channel, ++ch;
+        const long long in_a = static_cast<long long>(blk_a) * L, in_b = in_a + L;
+        // plain: both blocks exist, lie wholly inside ONE channel and neither is its block 0 (see fir_os_wave_kernel)
+        const bool plain = 2 * tile + 1 < total_blocks && blk_a != 0 && blk_b != 0 && in_b + kWaveN <= nn;
+        if (!plain) {
+            have_keep = false;
+            continue;
+        }
+        const float *pa = x + ch_a * n + static_cast<size_t>(in_a) + lane, *pb = pa + L;
+        c32 r[P];
+        if (have_keep) {
+#pragma unroll
+            for (int m = 0; m < 4 * I0; ++m) r[m].x = keep[m];
+        } else {
+#pragma unroll
+            for (int m = 0; m < 4 * I0; ++m) r[m].x = __builtin_nontemporal_load(pa + T * m);
+        }
+#pragma unroll
+        for (int m = 4 * I0; m < P; ++m) r[m].x = __builtin_nontemporal_load(pa + T * m);
+#pragma unroll
+        for (int m = 4 * I0; m < P; ++m) r[m].y = __builtin_nontemporal_load(pb + T * m);
+#pragma unroll
+        for (int m = 0; m < 4 * I0; ++m) r[m].y = r[m + P - 4 * I0].x;  // hop = whole rows: block b starts inside block a
+#pragma unroll
+        for (int m = 0; m < 4 * I0; ++m) keep[m] = r[m + P - 4 * I0].y;
+        have_keep = true;
+
+        fft4096_wave_quad<+1>(r, img, lane);
+#pragma unroll
+        for (int m = 0; m < P; ++m) {  // bin k = lane + 64 m
+            if (m < P / 2) r[m] = cmul(r[m], hlo[T * m]);
+            else r[m] = cmul_conj(r[m], hhi[-T * (m - P / 2)]);
+        }
+        fft4096_wave_quad<-1>(r, img, lane);
+
+        // outputs k in [256 * I0, 4096) of both blocks are kept; each plane is re-laid out through the image so that a lane
+        // owns 4 consecutive outputs and a wave instruction writes 1 KB
+        float *const ya = y + ch_a * n + static_cast<size_t>(in_a) + 4 * lane, *const yb = ya + L;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+#pragma unroll
+            for (int m = 4 * I0; m < P; ++m) img[(m - 4 * I0) * 64 + lane] = half ? r[m].y : r[m].x;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            f4 v[16 - I0];
+#pragma unroll
+            for (int i = I0; i < 16; ++i) v[i - I0] = *reinterpret_cast<const f4 *>(img + 256 * (i - I0) + 4 * lane);
+#pragma unroll
+            for (int i = I0; i < 16; ++i) __builtin_nontemporal_store(v[i - I0], reinterpret_cast<f4 *>((half ? yb : ya) + 256 * i));
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // centred moving average
 // ---------------------------------------------------------------------------------------------
@@ -972,12 +1080,41 @@ int launch_os(const float *x, float *y, size_t channels, size_t n, const c32 *d_
     if (log2n == 12 && tiles >= os_wave_min_tiles() && !hist && !ex.accumulate && !ex.zero_hist && ex.stride == n && ex.yoff == 0 &&
         (L & 255) == 0 && L >= 2048 && L <= 3840 && (n & 3) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0 &&
         (reinterpret_cast<uintptr_t>(x) & 3) == 0) {
-        // long signals: one wave per block pair, persistent workgroups (one per CU: four waves, one per SIMD)
         static const int cus = [] {
             int dev = 0, v = 256;
             if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev);
             return v;
         }();
+        // DSP_GPU_OS_WAVE_FORM=agpr: round 2's kernel (one wave per SIMD, WIDE transpose, prefetch into AGPRs by hand);
+        // default: two waves per SIMD, QUAD transpose, sequential runs (fir_os_wave2_kernel).  Identical bits.
+        const char *form = getenv("DSP_GPU_OS_WAVE_FORM");
+        if (!(form && form[0] == 'a') && (kOsN - L) / 256 <= 6) {  // (hops below 2560: the kept rows would spill registers)
+            // runs: whole rounds of one 8-wave workgroup per CU (a last round that fills a quarter of the chip costs as much
+            // as a full one), about 32 pairs to a run
+            const size_t per_round = static_cast<size_t>(cus) * kOsWave2Waves;
+            size_t rounds = (tiles + per_round * 16) / (per_round * 32);
+            if (rounds < 1) rounds = 1;
+            unsigned run_len = static_cast<unsigned>((tiles + per_round * rounds - 1) / (per_round * rounds));
+            if (const char *e = getenv("DSP_GPU_OS_WAVE_RUN"))  // tests: runs of several pairs on inputs too small to get them
+                if (atoi(e) > 0) run_len = static_cast<unsigned>(atoi(e));
+            const size_t runs = (tiles + run_len - 1) / run_len;
+            const size_t runs_per_xcd = ((runs + 7) / 8 + kOsWave2Waves - 1) / kOsWave2Waves * kOsWave2Waves;
+            const dim3 grid2(static_cast<unsigned>(runs_per_xcd / kOsWave2Waves * 8));
+#define DSPGPU_OSW2_CASE(I0)                                                                                            \
+    case I0: {                                                                                                          \
+        if (int rc = allow_full_lds(reinterpret_cast<const void *>(fir_os_wave2_kernel<I0>))) return rc;                \
+        hipLaunchKernelGGL(fir_os_wave2_kernel<I0>, grid2, dim3(kOsWave2Threads), kOsWave2LdsBytes, s, x, y, n, d_hspec, bpc, \
+                           total_blocks, tiles, run_len, runs_per_xcd);                                                 \
+    } break
+            switch (static_cast<int>((kOsN - L) / 256)) {
+                DSPGPU_OSW2_CASE(1); DSPGPU_OSW2_CASE(2); DSPGPU_OSW2_CASE(3); DSPGPU_OSW2_CASE(4);
+                DSPGPU_OSW2_CASE(5); DSPGPU_OSW2_CASE(6); DSPGPU_OSW2_CASE(7); DSPGPU_OSW2_CASE(8);
+            default: return fail(DSP_GPU_EINVAL, "fir_os_wave2_kernel: hop %lld", L);
+            }
+#undef DSPGPU_OSW2_CASE
+            if (int rc = check_launch("fir_os_wave2_kernel")) return rc;
+        } else {
+        // long signals: one wave per block pair, persistent workgroups (one per CU: four waves, one per SIMD)
         const size_t chunkw = (tiles + 7) / 8;
         size_t wgs = (static_cast<size_t>(cus) + 7) / 8 * 8;
         wgs = std::min(wgs, (chunkw + kOsWaveWaves - 1) / kOsWaveWaves * 8);
@@ -995,6 +1132,7 @@ int launch_os(const float *x, float *y, size_t channels, size_t n, const c32 *d_
         }
 #undef DSPGPU_OSW_CASE
         if (int rc = check_launch("fir_os_wave_kernel")) return rc;
+        }
         // the pairs it left out -- those holding a channel's first or last block -- on the workgroup kernel: two per channel
         OsExtra edge = ex;
         edge.edge_pairs = 1;

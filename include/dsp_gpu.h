@@ -111,7 +111,8 @@ int dsp_gpu_fft_batch_f64(const void *in, void *out, int log2n, size_t batch, in
  * transforms of more than 2^15 points ping-pong through is a fixed 16 MiB device array inside the library (2^21 complex
  * points, held by every GPU the library runs on until the process ends) instead of the growing workspace, and the call
  * makes no hipMalloc / hipFree.  1 <= log2n <= 21; for log2n >= 16, batch * 2^log2n <= 2^21 points (DSP_GPU_EINVAL
- * beyond that; transforms of up to 2^15 points use no scratch and take any batch).  Every call on a GPU shares that
+ * beyond that; transforms of up to 2^15 points use no scratch and take any batch -- except under the development
+ * switch DSP_GPU_FFT_PLANE=0, which sends 2^15-point transforms down the two-pass route and so under the same limit).  Every call on a GPU shares that
  * GPU's array: calls that overlap on one GPU (two streams, two threads) race.  The first call on a device looks up the
  * array's address (hipGetSymbolAddress) -- make it once outside a graph capture.
  */

@@ -364,6 +364,17 @@ def test_overlap_save_wave_kernel(ops, dev, orc, channels, n, ntaps, monkeypatch
     assert (g[0] == 9).all() and (g[-1] == 9).all()
     assert rel_l2(g[1:-1], want) <= OS_TOL
     assert (g[1:-1, :ntaps - 1] == 0).all()
+    # the two forms of the wave kernel (round 2: one wave per SIMD, prefetch into AGPRs; round 3, the default: two waves
+    # per SIMD, QUAD transpose, runs of consecutive pairs that keep the shared samples in registers) give the same bits --
+    # with runs of one pair (what inputs this small get) and with runs of 2, 3 and 7 pairs (kept rows in use)
+    monkeypatch.setenv("DSP_GPU_OS_WAVE_FORM", "agpr")
+    old_form = ops.convolve(xd, h, "overlap_save").cpu().numpy()
+    monkeypatch.delenv("DSP_GPU_OS_WAVE_FORM")
+    assert np.array_equal(g[1:-1], old_form)
+    for run in (2, 3, 7):
+        monkeypatch.setenv("DSP_GPU_OS_WAVE_RUN", str(run))
+        assert np.array_equal(ops.convolve(xd, h, "overlap_save").cpu().numpy(), old_form), run
+    monkeypatch.delenv("DSP_GPU_OS_WAVE_RUN")
     monkeypatch.setenv("DSP_GPU_OS_WAVE_MIN_TILES", "999999999")
     other = ops.convolve(xd, h, "overlap_save").cpu().numpy()
     assert rel_l2(g[1:-1], other) <= 5e-6
