@@ -834,7 +834,8 @@ DSP_DEV int ma_pad(int i) { return i + ((i >> 4) * Smp<T>::kVec); }
 // eval/moving_average_filter_demo/main.cpp:14).
 template <bool ALIGNED, int kMaPer, typename T = float>
 __global__ __launch_bounds__(kThreads) void moving_average_kernel(const T *__restrict__ x, T *__restrict__ y,
-                                                                  size_t n, int npoints, int span, int cpt) {
+                                                                  size_t n, int npoints, int span, int cpt, int skip_lo,
+                                                                  int skip_n) {
     using V = typename Smp<T>::vec;
     constexpr int kVec = Smp<T>::kVec;
     constexpr int kMaTile = kThreads * kMaPer;
@@ -851,7 +852,9 @@ __global__ __launch_bounds__(kThreads) void moving_average_kernel(const T *__res
     // XCD-contiguous tiles along the channel (workgroups x and x + 8 share an XCD).  Worth 1 %; plain (cached) loads
     // would let the neighbouring tile's window halo come out of L2 (traffic 8.55 -> 8.01 GiB) but run 3 % slower
     // than streaming loads
-    const unsigned bx = (gridDim.x & 7u) == 0 ? (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+    // (skip_n > 0: this launch covers only the tiles outside [skip_lo, skip_lo + skip_n), which moving_average_seq_kernel takes)
+    const unsigned bx = skip_n > 0 ? blockIdx.x + (static_cast<int>(blockIdx.x) >= skip_lo ? skip_n : 0)
+                                   : ((gridDim.x & 7u) == 0 ? (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x);
     const long long out0 = static_cast<long long>(bx) * kMaTile;  // first output of the tile
     const long long first = out0 - mid;                                   // first sample the tile needs
     const long long seg0 = first & ~static_cast<long long>(kVec - 1);     // staged from here (16-byte aligned)
@@ -972,6 +975,144 @@ __global__ __launch_bounds__(kThreads) void moving_average_kernel(const T *__res
             v = mean(sum);
         }
         __builtin_nontemporal_store(v, yc + j);
+    }
+}
+
+// Round 3: the same filter with every sample read ONCE.  A workgroup walks a run of consecutive interior tiles of one
+// channel (4096 outputs each) and carries the window's worth of samples that two neighbouring tiles share from tile to
+// tile inside LDS -- in the prefix form they are already in (an in-chunk exclusive prefix depends on its chunk alone; the
+// chunk prefixes are rebased) -- instead of staging them again from HBM / L2 (traffic 1.04x -> 1.01x of 8 B/sample, reads at
+// the L2 1.125x -> 1.008x).  Only the 4096 new samples of a tile are loaded, scanned (one chunk per thread) and the next
+// tile's are already on their way (registers) while this tile's outputs are formed.  Tiles whose window leaves the channel
+// (the first one or two and the last ones) stay with moving_average_kernel.  Same arithmetic per output, except that the
+// double chunk prefixes of a run's later tiles carry the rebased values of the earlier one (differences of doubles: exact
+// to ~1e-16 relative, far inside the 1e-6 budget).
+template <typename T>
+__global__ __launch_bounds__(kThreads) void moving_average_seq_kernel(const T *__restrict__ x, T *__restrict__ y, size_t n,
+                                                                      int npoints, int span, int tile_lo, int tile_n, int run) {
+    using V = typename Smp<T>::vec;
+    constexpr int kVec = Smp<T>::kVec;
+    constexpr int kTile = kThreads * kMaPerMax;  // 4096 outputs
+    constexpr int kNew = kTile / 16;             // 256 new chunks per tile: one per thread
+    constexpr int kLoads = 16 / kVec;            // 16-byte loads per thread and tile
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int chunks = span >> 4, carried = chunks - kNew;
+    T *xs = reinterpret_cast<T *>(smem_raw);
+    double *pc = reinterpret_cast<double *>(xs + ma_pad<T>(span));  // chunks + 1 entries: pc[chunks] = total of the span
+    double *wave_tot = pc + chunks + 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const size_t ch = blockIdx.y;
+    const int t0 = tile_lo + static_cast<int>(blockIdx.x) * run;
+    const int count = min(run, tile_lo + tile_n - t0);
+    const long long mid = npoints / 2;
+    const int window = 2 * static_cast<int>(mid) + 1;
+    const T *xc = x + ch * n;
+    T *yc = y + ch * n;
+    const long long nn = static_cast<long long>(n);
+    const T corr = ((npoints & 1) == 0 && npoints < nn) ? xc[npoints] : T(0);
+    const double inv = 1.0 / static_cast<double>(npoints), dcorr = static_cast<double>(corr);
+    const long long first0 = static_cast<long long>(t0) * kTile - mid;
+    const long long seg0 = first0 & ~static_cast<long long>(kVec - 1);
+    const int shift = static_cast<int>(first0 - seg0);  // the same for every tile: kTile is a multiple of the group
+
+    // in-chunk exclusive prefixes of chunks [c_first + tid + 256 k], k < rounds, then the block scan of their totals in
+    // double; pc[c] = base + (sum of the chunks before c); returns base + (sum of all of them)
+    auto scan_chunks = [&](int c_first, int rounds, double base) {
+        for (int k = 0; k < rounds; ++k) {
+            const int c = c_first + tid + kThreads * k;
+            T run_sum = T(0);
+            if (c < chunks) {
+#pragma unroll
+                for (int q = 0; q < 16 / kVec; ++q) {
+                    V *p = reinterpret_cast<V *>(xs + ma_pad<T>(16 * c + kVec * q));
+                    const V v = *p;
+                    V e;
+#pragma unroll
+                    for (int i = 0; i < kVec; ++i) {
+                        e[i] = run_sum;
+                        run_sum = run_sum + v[i];
+                    }
+                    *p = e;
+                }
+            }
+            const double mine = static_cast<double>(run_sum);
+            double incl = mine;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const double o = shfl_up_f64(incl, d);
+                if (lane >= d) incl += o;
+            }
+            if (lane == 63) wave_tot[4 * k + wave] = incl;
+            __syncthreads();
+            double running = base + (incl - mine);
+            for (int w = 0; w < wave; ++w) running += wave_tot[4 * k + w];
+            if (c < chunks) pc[c] = running;
+            base += wave_tot[4 * k] + wave_tot[4 * k + 1] + wave_tot[4 * k + 2] + wave_tot[4 * k + 3];
+        }
+        if (tid == 0) pc[chunks] = base;
+        return base;
+    };
+    auto emit = [&](long long out0) {
+        T *yt = yc + out0;
+        // (opaque per call: otherwise the compiler hoists the 64 LDS addresses of this loop out of the tile loop and the
+        // kernel needs 132 registers instead of ~40 -- three workgroups per CU instead of six)
+        int sh = shift;
+        asm volatile("" : "+v"(sh));
+#pragma unroll
+        for (int i = 0; i < kMaPerMax; ++i) {
+            const int jrel = kThreads * i + tid;
+            const int lo = jrel + sh, up = lo + window;
+            const double sum = (pc[up >> 4] - pc[lo >> 4]) +
+                               (static_cast<double>(xs[ma_pad<T>(up)]) - static_cast<double>(xs[ma_pad<T>(lo)]));
+            if constexpr (sizeof(T) == 8) __builtin_nontemporal_store((sum - dcorr) / static_cast<double>(npoints), yt + jrel);
+            else __builtin_nontemporal_store(static_cast<T>((sum - dcorr) * inv), yt + jrel);
+        }
+    };
+    const T *newp = xc + seg0 + 16 * carried + tid * kVec;  // this thread's first new sample of tile 0 (as if it were a later tile)
+    auto load_new = [&](V (&v)[kLoads], int k) {
+#pragma unroll
+        for (int i = 0; i < kLoads; ++i) v[i] = load_stream<T>(newp + static_cast<long long>(k) * kTile + i * kThreads * kVec);
+    };
+
+    // tile 0 of the run: the whole span from memory
+    {
+        constexpr int kStep = kThreads * kVec;
+        int u0 = tid * kVec;
+        for (; u0 + 3 * kStep < span; u0 += 4 * kStep) {
+            V v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = load_stream<T>(xc + seg0 + u0 + i * kStep);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) *reinterpret_cast<V *>(xs + ma_pad<T>(u0 + i * kStep)) = v[i];
+        }
+        for (int u = u0; u < span; u += kStep) *reinterpret_cast<V *>(xs + ma_pad<T>(u)) = load_stream<T>(xc + seg0 + u);
+    }
+    V nxt[kLoads];
+    if (count > 1) load_new(nxt, 1);
+    __syncthreads();
+    scan_chunks(0, (chunks + kThreads - 1) / kThreads, 0.0);
+    __syncthreads();
+    emit(static_cast<long long>(t0) * kTile);
+
+    for (int k = 1; k < count; ++k) {
+        __syncthreads();  // every output of the previous tile has been formed
+        // carry: chunks [256, chunks) become chunks [0, carried): their in-chunk prefixes as they are, chunk prefixes rebased
+        // (carried < 256, so source and destination never overlap)
+        {
+            const int rec = 16 + kVec;  // samples + pad of one chunk in the padded image
+            const int nvec = carried * rec / kVec;
+            for (int v = tid; v < nvec; v += kThreads)
+                *reinterpret_cast<V *>(xs + v * kVec) = *reinterpret_cast<const V *>(xs + kNew * rec + v * kVec);
+            if (tid <= carried) pc[tid] = pc[kNew + tid] - pc[kNew];
+        }
+        // the new samples (in flight since the previous tile) behind them
+#pragma unroll
+        for (int i = 0; i < kLoads; ++i) *reinterpret_cast<V *>(xs + ma_pad<T>(16 * carried + tid * kVec + i * kThreads * kVec)) = nxt[i];
+        if (k + 1 < count) load_new(nxt, k + 1);
+        __syncthreads();
+        scan_chunks(carried, 1, pc[carried]);
+        __syncthreads();
+        emit(static_cast<long long>(t0 + k) * kTile);
     }
 }
 
@@ -1204,7 +1345,7 @@ int launch_moving_average_t(const T *x, T *y, size_t channels, size_t n, int npo
     const size_t lds_bytes = static_cast<size_t>(span + (span / 16) * kVec) * sizeof(T) + static_cast<size_t>(chunks + 4 * cpt) * sizeof(double);
     const size_t blocks = (n + tile - 1) / tile;
     const bool aligned = (n % kVec == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0);
-    void (*kern)(const T *, T *, size_t, int, int, int) = nullptr;
+    void (*kern)(const T *, T *, size_t, int, int, int, int, int) = nullptr;
 #define DSPGPU_MA_PICK(PER) kern = aligned ? moving_average_kernel<true, PER, T> : moving_average_kernel<false, PER, T>
     switch (per) {
     case 1: DSPGPU_MA_PICK(1); break;
@@ -1216,7 +1357,35 @@ int launch_moving_average_t(const T *x, T *y, size_t channels, size_t n, int npo
 #undef DSPGPU_MA_PICK
     if (lds_bytes > 64 * 1024)
         if (int rc = allow_full_lds(reinterpret_cast<const void *>(kern))) return rc;
-    hipLaunchKernelGGL(kern, dim3(blocks, channels), dim3(kThreads), lds_bytes, s, x, y, n, npoints, span, cpt);
+    // DSP_GPU_MAVG_SEQ=1 (opt-in, read per call): on long channels the interior tiles -- window wholly inside the channel --
+    // go to the sequential kernel in runs of 16 (every sample read once: HBM traffic 1.04x -> 1.01x of the algorithmic 8 B per
+    // sample), the first and last few stay here.  Not the default: it moves fewer bytes but runs 9-13 % slower on C3's shape
+    // (1.61-1.66 ms against 1.47: profiles/r03_mavg_sequential_ab.txt) -- the tile loop serialises what independent
+    // one-tile workgroups overlap.
+    const char *seq_env = getenv("DSP_GPU_MAVG_SEQ");
+    const bool seq_on = seq_env && seq_env[0] == '1';
+    if (seq_on && aligned && per == kMaPerMax && window + kVec <= tile / 2) {
+        const long long mid = npoints / 2;
+        const long long lo = (mid + kVec + tile - 1) / tile;  // first tile whose staged span starts inside the channel
+        // last tile t with t*tile - mid - (kVec-1) + span <= n (the span ends inside) and (t+1)*tile <= n - mid (full windows)
+        const long long hi_a = (static_cast<long long>(n) - span + mid) / tile;
+        const long long hi_b = (static_cast<long long>(n) - mid) / tile - 1;
+        const long long hi = std::min(hi_a, hi_b);
+        if (hi - lo + 1 >= 8) {
+            const int tile_n = static_cast<int>(hi - lo + 1), run = 16;
+            const unsigned runs = static_cast<unsigned>((tile_n + run - 1) / run);
+            const size_t lds_seq = static_cast<size_t>(span + (span / 16) * kVec) * sizeof(T) + static_cast<size_t>(chunks + 1 + 4 * cpt) * sizeof(double);
+            auto kseq = moving_average_seq_kernel<T>;
+            if (lds_seq > 64 * 1024)
+                if (int rc = allow_full_lds(reinterpret_cast<const void *>(kseq))) return rc;
+            hipLaunchKernelGGL(kseq, dim3(runs, channels), dim3(kThreads), lds_seq, s, x, y, n, npoints, span, static_cast<int>(lo), tile_n, run);
+            if (int rc = check_launch("moving_average_seq_kernel")) return rc;
+            const size_t edge = blocks - static_cast<size_t>(tile_n);
+            if (edge) hipLaunchKernelGGL(kern, dim3(edge, channels), dim3(kThreads), lds_bytes, s, x, y, n, npoints, span, cpt, static_cast<int>(lo), tile_n);
+            return check_launch("moving_average_kernel (edge tiles)");
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3(blocks, channels), dim3(kThreads), lds_bytes, s, x, y, n, npoints, span, cpt, 0, 0);
     return check_launch("moving_average_kernel");
 }
 }  // namespace

@@ -5,7 +5,7 @@
 #   rocprofv3 --pmc <SQ counters>               (two passes: where the waves' cycles go, LDS conflicts)
 # Results land in gpurun_out/prof_$ROUND/<workload>/ ; scripts/profile_collect.py turns them into profiles/.
 set -e
-ROUND=${ROUND:-r02}
+ROUND=${ROUND:-r03}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 ROOT=gpurun_out/prof_$ROUND
 B="--no-cpu-baseline --no-secondary"

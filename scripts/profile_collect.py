@@ -7,9 +7,9 @@ profiles/traffic.json                          HBM bytes per launch of the domin
 usage: profile_collect.py [round]   (default r02)"""
 import csv, glob, json, os, shutil, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ROUND = sys.argv[1] if len(sys.argv) > 1 else "r02"
+ROUND = sys.argv[1] if len(sys.argv) > 1 else "r03"
 SRC = os.path.join(ROOT, "gpurun_out", f"prof_{ROUND}")
-KERNEL = {"fft": "fft_lds_kernel", "fir_direct": "fir_direct_kernel", "fir_os": "fir_os_wave_kernel",
+KERNEL = {"fft": "fft_lds_kernel", "fir_direct": "fir_direct_kernel", "fir_os": "fir_os_wave2_kernel",
           "mavg": "moving_average_kernel", "iir_batch": "iir_batch_kernel", "iir_scan": "iir_scan_kernel",
           "fft_dist": "fft_column_kernel", "fft_32k": "fft_plane_kernel", "fft_real_64k": "fft_plane_kernel",
           "fft_f64": "fft64_tile_kernel", "biquad_swept": "biquad_swept_kernel",

@@ -125,6 +125,20 @@ def test_moving_average_golden_double(ops, dev, golden):
     assert np.array_equal(got, ops.moving_average_f64(x, 511))  # host-pointer route
 
 
+@pytest.mark.parametrize("channels,n,npoints", [(2, 4096 * 33 + 1000, 511), (1, 1 << 18, 64), (3, 4096 * 20, 2045)])
+def test_moving_average_sequential_kernel_double(ops, dev, orc, channels, n, npoints, monkeypatch):
+    """Long channels: moving_average_seq_kernel<double> (see tests/test_fir_gpu.py::test_mavg_sequential_kernel)."""
+    import torch
+    monkeypatch.setenv("DSP_GPU_MAVG_SEQ", "1")
+    rng = np.random.default_rng(n + npoints)
+    x = rng.standard_normal((channels, n))
+    got = ops.moving_average_f64(torch.from_numpy(x).to(dev), npoints).cpu().numpy()
+    want = orc.moving_average(x, npoints)
+    assert rel_l2(got, want) <= 1e-12
+    for lo in range(0, n - 4096, 4096):
+        assert rel_l2(got[:, lo:lo + 4096], want[:, lo:lo + 4096]) <= 1e-11, lo
+
+
 @pytest.mark.parametrize("channels,n,npoints", [(1, 16, 5), (3, 1000, 8), (2, 4097, 511), (5, 300, 1), (1, 9000, 2048), (70, 129, 33),
                                                 (1, 511, 511), (2, 20001, 8191)])
 def test_moving_average_ragged_double(ops, dev, orc, channels, n, npoints):

@@ -156,6 +156,29 @@ def test_mavg_vs_oracle(ops, dev, orc, channels, n, pts):
         assert not got[:, n - mid:].any()
 
 
+@pytest.mark.parametrize("channels,n,pts", [(2, 4096 * 40 + 1236, 511), (3, 1 << 18, 8), (1, 4096 * 30, 2043), (2, 4096 * 25 + 4, 100),
+                                            (1, 4096 * 9 + 2048, 1), (5, 4096 * 21, 1024), (1, 1 << 20, 511)])
+def test_mavg_sequential_kernel(ops, dev, orc, channels, n, pts, monkeypatch):
+    """Channels long enough for moving_average_seq_kernel (runs of consecutive interior tiles, the shared samples carried in
+    LDS; the first and last tiles of a channel on the one-tile kernel): runs of 16 tiles and shorter last runs, odd and even
+    windows, a window of one sample, the largest window it takes, ragged channel ends."""
+    import torch
+    monkeypatch.setenv("DSP_GPU_MAVG_SEQ", "1")  # opt-in kernel (fewer bytes, slower: DESIGN.md 4.4)
+    rng = np.random.default_rng(n + pts)
+    x = rng.standard_normal((channels, n)).astype(np.float32)
+    guard = torch.full((channels + 2, n), 7.0, device=dev)
+    ops.moving_average(torch.from_numpy(x).to(dev), pts, out=guard[1:-1])
+    g = guard.cpu().numpy()
+    assert (g[0] == 7).all() and (g[-1] == 7).all()
+    want = orc.moving_average(x.astype(np.float64), pts)
+    assert rel_l2(g[1:-1], want) <= 1e-6, (n, pts)
+    # tile by tile too: a carry that went wrong shows in one tile of a run, which an L2 norm over a megasample would forgive
+    for lo in range(0, n - 4096, 4096):
+        assert rel_l2(g[1:-1, lo:lo + 4096], want[:, lo:lo + 4096]) <= 2e-6 or not want[:, lo:lo + 4096].any(), lo
+    mid = pts // 2
+    assert not g[1:-1, :mid].any() and not g[1:-1, n - mid:].any()
+
+
 def test_mavg_golden(ops, dev, golden):
     import torch
     x = golden["fir_noise_in"]
