@@ -129,3 +129,34 @@ def test_iir_random_shapes(ops, dev, orc, seed):
             g = st.cpu().numpy()
             assert np.allclose(g[:, :poles], so[:, 1:poles + 1])
             assert np.allclose(g[:, poles:], so[:, poles + 2:], rtol=1e-6, atol=1e-9), (mode, poles, channels, n)
+
+
+@pytest.mark.parametrize("seed", range(SEEDS))
+def test_double_sample_filters_random_shapes(ops, dev, orc, seed):
+    """SampleBuffer<double> forms (dsp_gpu_convolve_f64 / moving_average_f64 / iir_f64): ragged shapes against the oracle's
+    double functions at double tolerances (sums in another order: a few ulp; the recursion amplifies them a little)."""
+    import torch
+    rng = np.random.default_rng(4000 + seed)
+    for _ in range(5):
+        channels, n = int(rng.integers(1, 40)), int(rng.integers(1, 9000))
+        x = rng.standard_normal((channels, n))
+        xd = torch.from_numpy(x).to(dev)
+        ntaps = int(rng.integers(1, 600))
+        h = rng.standard_normal(ntaps) / np.sqrt(ntaps)
+        want = orc.fir(x, h)
+        got = ops.convolve_f64(xd, h, "direct").cpu().numpy()
+        assert rel_l2(got, want) <= 1e-13 or not want.any(), ("fir", channels, n, ntaps)
+        assert not got[:, : min(ntaps - 1, n)].any()
+        pts = int(rng.integers(1, min(1200, n) + 1))  # n < npoints is refused (the reference reads out of bounds there)
+        want = orc.moving_average(x, pts)
+        got = ops.moving_average_f64(xd, pts).cpu().numpy()
+        assert rel_l2(got, want) <= 1e-11 or not want.any(), ("mavg", channels, n, pts)
+        poles = int(rng.integers(1, 9))
+        a, b = _stable_section(rng, poles)
+        want = orc.iir(x, a, b)
+        for mode in ("batch", "auto"):
+            got = ops.iir_f64(xd, a, b, mode=mode).cpu().numpy()
+            assert rel_l2(got, want) <= 1e-11 or not want.any(), ("iir", mode, poles, channels, n)
+        # the reference's own arithmetic: bit for bit (two poles = Coefficients<2>, the BiQuad specialisation: coefficients.h:172-182)
+        want_ref = orc.biquad(x, a, b) if poles == 2 else want
+        assert np.array_equal(ops.iir_f64(xd, a, b, mode="batch_ref").cpu().numpy(), want_ref), ("iir ref", poles, channels, n)
