@@ -165,9 +165,11 @@ std::vector<std::complex<float>> fft_rows(const float *rows, size_t n_in, size_t
 }
 
 // fft.h:85-94 (a copy on the host: the reference's shift has no arithmetic to accelerate; the fused
-// device form is the `shifted` flag above).
-inline std::vector<std::complex<float>> shift(std::vector<std::complex<float>> data) {
-    std::vector<std::complex<float>> out(data.size());
+// device form is the `shifted` flag above).  The reference declares it for std::vector<std::complex<double>>; any
+// complex sample type is taken.
+template <typename Real>
+inline std::vector<std::complex<Real>> shift(std::vector<std::complex<Real>> data) {
+    std::vector<std::complex<Real>> out(data.size());
     const size_t n = data.size(), mid = n / 2;
     for (size_t i = 0; i < n; ++i) out[(i + mid) % n] = data[i];
     return out;

@@ -105,6 +105,11 @@ int main(int argc, char **argv) {
                 for (size_t i = 0; i < out.size(); ++i) streamed.add(out[static_cast<int>(i)]);
             }
             dump(dir + "/sinc_lp_streamed.f64", streamed.data(), streamed.size());
+            // dsp::shift on the spectrum type the reference declares it for (fft.h:85: std::vector<std::complex<double>>)
+            std::vector<std::complex<double>> spec(1024);
+            dsp::fft(input.begin(), input.begin() + 1000, spec.begin(), 1024);
+            std::vector<std::complex<double>> centred = dsp::shift(spec);
+            dump(dir + "/spectrum_shifted.c64", reinterpret_cast<const double *>(centred.data()), 2 * centred.size());
         }
     } catch (const std::exception &e) {
         std::fprintf(stderr, "reference_callers_check: %s\n", e.what());

@@ -149,6 +149,8 @@ def test_reference_callers_on_gpu(tmp_path, orc, dev):
         assert rel_l2(rd(f"mavg_{size}.f64"), orc.moving_average(noise, size)) <= 1e-12, size
     assert rel_l2(rd("sinc_hp.f64"), orc.fir(noise, orc.sinc(0.2, 200, inversion="inversion"))) <= 1e-13
     assert rel_l2(rd("sinc_lp_streamed.f64"), orc.fir(noise, orc.sinc(0.14, 200))) <= 1e-13
+    shifted = rd("spectrum_shifted.c64").view(np.complex128)
+    assert rel_l2(shifted, orc.shift(orc.fft_real(noise[:1000], 1024))) <= 1e-13
 
 
 def test_swept_cos_matches_libm():
