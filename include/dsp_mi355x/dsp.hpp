@@ -415,7 +415,7 @@ struct Coefficients {
     // SampleBuffer<double>.  mode DSP_GPU_IIR_BATCH_REF reproduces the reference's arithmetic bit for bit (for float
     // buffers the generic section then accumulates in float, coefficients.h:108-118); the default computes in double
     // with fused multiply-adds.
-    template <typename Buffer>
+    template <typename Buffer, std::enable_if_t<!std::is_arithmetic_v<Buffer>, int> = 0>
     Buffer operator()(const Buffer &input, int mode = DSP_GPU_IIR_AUTO) {
         assert(b[0] == 0);
         Buffer output(input.size());
@@ -441,13 +441,47 @@ struct Coefficients {
         return output;
     }
 
+    // coefficients.h:106-130 (generic) / :172-182 (BiQuad): ONE sample, continuing from and updating x[] / y[] -- the call
+    // the wind generator makes per sample (eval/signals/wind_generator.h:44,73,123,164).  It goes through the same device
+    // entry point as a buffer of one sample, in the reference's own arithmetic (DSP_GPU_IIR_BATCH_REF: bit-identical to the
+    // reference's step, float accumulator for float samples), so a caller that steps sample by sample compiles and gets the
+    // reference's bits -- at ~40 us a call.  It exists for completeness: hand over blocks (or use bandPassSwept for a
+    // filter retuned every sample) wherever the caller's structure allows.
+    template <typename SampleType, std::enable_if_t<std::is_floating_point_v<SampleType>, int> = 0>
+    SampleType operator()(SampleType iSample) {
+        std::array<double, 2 * Poles> st{};
+        for (size_t i = 0; i < Poles; ++i) {
+            st[i] = x[i + 1];
+            st[Poles + i] = y[i + 1];
+        }
+        SampleType out{};
+        if constexpr (std::is_same_v<SampleType, double>)
+            check(dsp_gpu_iir_f64(&iSample, &out, 1, 1, a.data(), b.data(), static_cast<int>(Poles), c0, d0, st.data(),
+                                  DSP_GPU_IIR_BATCH_REF, DSP_GPU_MEM_HOST, nullptr),
+                  "Coefficients::operator()(sample)");
+        else {
+            const float in = static_cast<float>(iSample);
+            float o = 0.0f;
+            check(dsp_gpu_iir(&in, &o, 1, 1, a.data(), b.data(), static_cast<int>(Poles), c0, d0, st.data(), DSP_GPU_IIR_BATCH_REF,
+                              DSP_GPU_MEM_HOST, nullptr),
+                  "Coefficients::operator()(sample)");
+            out = static_cast<SampleType>(o);
+        }
+        for (size_t i = 0; i < Poles; ++i) {
+            x[i + 1] = st[i];
+            y[i + 1] = st[Poles + i];
+        }
+        x[0] = 0;  // coefficients.h:126
+        return out;
+    }
+
     // coefficients.h:132-170 (generic) and :197-206 (BiQuad): the block-streaming form of the audio callbacks
     // (eval/recursive_filters/main.cpp:174-206) -- filter one block, continuing from the object's history, and
     // write sample i to output[i]; `output` is any indexable sink, the reference's CircularBuffer<T, Capacity>
     // (whose operator[] wraps) included.  Not reproduced from the generic overload: its function-static input
     // history shared by every filter object (:142), feedback taken from the already wet/dry-mixed ring (:162-165)
     // and the X[i] index slip (:165); this is the recursion of :106-130 block by block, as the BiQuad overload is.
-    template <typename Buffer, typename Sink>
+    template <typename Buffer, typename Sink, std::enable_if_t<!std::is_arithmetic_v<Sink>, int> = 0>
     void operator()(const Buffer &input, Sink &output, int mode = DSP_GPU_IIR_AUTO) {
         const Buffer block = (*this)(input, mode);
         for (size_t i = 0; i < input.size(); ++i) output[static_cast<int>(i)] = block[static_cast<int>(i)];

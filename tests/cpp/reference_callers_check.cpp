@@ -105,6 +105,24 @@ int main(int argc, char **argv) {
                 for (size_t i = 0; i < out.size(); ++i) streamed.add(out[static_cast<int>(i)]);
             }
             dump(dir + "/sinc_lp_streamed.f64", streamed.data(), streamed.size());
+            // sample by sample, as the wind generator steps its filters (eval/signals/wind_generator.h:44,73,123,164):
+            // Coefficients<P>::operator()(SampleType), coefficients.h:106-130 / 172-182
+            {
+                auto lop = dsp::recursive::lowPassFilter<4>(0.1);
+                auto bp = dsp::recursive::bandPassFilter(0.1, 0.01);
+                std::vector<double> s4, s2;
+                std::vector<float> s4f;
+                auto lopf = dsp::recursive::lowPassFilter<4>(0.1);
+                for (size_t i = 0; i < 64; ++i) {
+                    s4.push_back(lop(input[static_cast<int>(i)]));
+                    s2.push_back(bp(input[static_cast<int>(i)]));
+                    s4f.push_back(lopf(static_cast<float>(input[static_cast<int>(i)])));
+                }
+                dump(dir + "/per_sample_lp4.f64", s4.data(), s4.size());
+                dump(dir + "/per_sample_bp.f64", s2.data(), s2.size());
+                std::vector<double> widened(s4f.begin(), s4f.end());
+                dump(dir + "/per_sample_lp4_float.f64", widened.data(), widened.size());
+            }
             // dsp::shift on the spectrum type the reference declares it for (fft.h:85: std::vector<std::complex<double>>)
             std::vector<std::complex<double>> spec(1024);
             dsp::fft(input.begin(), input.begin() + 1000, spec.begin(), 1024);

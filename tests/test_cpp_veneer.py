@@ -149,6 +149,11 @@ def test_reference_callers_on_gpu(tmp_path, orc, dev):
         assert rel_l2(rd(f"mavg_{size}.f64"), orc.moving_average(noise, size)) <= 1e-12, size
     assert rel_l2(rd("sinc_hp.f64"), orc.fir(noise, orc.sinc(0.2, 200, inversion="inversion"))) <= 1e-13
     assert rel_l2(rd("sinc_lp_streamed.f64"), orc.fir(noise, orc.sinc(0.14, 200))) <= 1e-13
+    # per-sample calls: the reference's step bit for bit (generic section and BiQuad; float samples accumulate in float)
+    assert np.array_equal(rd("per_sample_lp4.f64"), orc.iir(noise[:64], a4, b4))
+    abp, bbp, c0bp, d0bp = designs_bp = orc.biquad_design("bandpass", 0.1, 0.01)
+    assert np.array_equal(rd("per_sample_bp.f64"), orc.biquad(noise[:64], abp, bbp, c0bp, d0bp))
+    assert np.array_equal(rd("per_sample_lp4_float.f64"), orc.iir(noise[:64].astype(np.float32), a4, b4).astype(np.float64))
     shifted = rd("spectrum_shifted.c64").view(np.complex128)
     assert rel_l2(shifted, orc.shift(orc.fft_real(noise[:1000], 1024))) <= 1e-13
 
