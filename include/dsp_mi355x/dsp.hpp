@@ -54,38 +54,92 @@ inline void check(int rc, const char *what) {
     if (rc != DSP_GPU_OK) throw std::runtime_error(std::string(what) + ": " + dsp_gpu_last_error_string());
 }
 
-// ---- sample container (sample_buffer.h:14-133, the part the hot path uses) ----------------------
+// ---- sample container (sample_buffer.h:14-182) ----------------------------------------------------
+// The argument and return type of every filter signature: an owning, contiguous array of floating-point samples.
+// Same template parameters, members and aliases as the reference's, so code written against it compiles here:
+// Circular buffers wrap their index ((size + idx) % size, sample_buffer.h:67-83 -- what the audio callbacks' ring of
+// `Capacity` frames relies on) and are born with `Capacity` samples; plain ones grow with add().  Two slips of the
+// reference are not reproduced: add(buffer) copies buffer.size() ELEMENTS (the reference memcpy's that many bytes,
+// :57-61), and view() returns the view it declares (the reference's definition constructs a SampleBuffer, :169-173, and
+// cannot be instantiated).
 template <typename SampleType>
+class SampleBufferView {
+  public:
+    SampleBufferView(const SampleType *first, const SampleType *last) : m_first(first), m_last(last) {}
+    size_t size() const noexcept { return static_cast<size_t>(m_last - m_first); }
+    const SampleType &operator[](int i) const { return m_first[i]; }
+    explicit operator const SampleType *() const noexcept { return m_first; }
+    const SampleType *data() const noexcept { return m_first; }
+    const SampleType *cbegin() const noexcept { return m_first; }
+    const SampleType *cend() const noexcept { return m_last; }
+    const SampleType *begin() const noexcept { return m_first; }
+    const SampleType *end() const noexcept { return m_last; }
+
+  private:
+    const SampleType *m_first, *m_last;
+};
+
+template <typename SampleType, bool Circular = false, size_t Capacity = 0>
 class SampleBuffer {
     static_assert(std::is_floating_point<SampleType>::value, "SampleType should be floating point type");
 
   public:
-    SampleBuffer() = default;
+    SampleBuffer() : m_data(Circular ? Capacity : 0) {}
     explicit SampleBuffer(size_t size) : m_data(size) {}
     SampleBuffer(size_t size, SampleType val) : m_data(size, val) {}
-    template <typename It>
+    template <typename It, typename = typename std::iterator_traits<It>::iterator_category>
     SampleBuffer(It first, It last) : m_data(first, last) {}
-    void add(SampleType s) { m_data.push_back(s); }
+    template <bool C2, size_t Cap2>
+    SampleBuffer(const SampleBuffer<SampleType, C2, Cap2> &other) : m_data(other.begin(), other.end()) {}
+
+    void add(SampleType s) {
+        static_assert(!Circular, "a circular buffer has a fixed number of slots");
+        m_data.push_back(s);
+    }
+    template <bool C2, size_t Cap2>
+    void add(const SampleBuffer<SampleType, C2, Cap2> &other) {
+        static_assert(!Circular, "a circular buffer has a fixed number of slots");
+        m_data.insert(m_data.end(), other.begin(), other.end());
+    }
     size_t size() const noexcept { return m_data.size(); }
-    SampleType &operator[](int i) { return m_data[static_cast<size_t>(i)]; }
-    const SampleType &operator[](int i) const { return m_data[static_cast<size_t>(i)]; }
+    SampleType &operator[](int i) { return m_data[slot(i)]; }
+    const SampleType &operator[](int i) const { return m_data[slot(i)]; }
+    explicit operator SampleType *() noexcept { return m_data.data(); }
+    explicit operator const SampleType *() const noexcept { return m_data.data(); }
     SampleType *data() noexcept { return m_data.data(); }
     const SampleType *data() const noexcept { return m_data.data(); }
     auto begin() noexcept { return m_data.begin(); }
     auto end() noexcept { return m_data.end(); }
     auto begin() const noexcept { return m_data.begin(); }
     auto end() const noexcept { return m_data.end(); }
+    auto cbegin() const noexcept { return m_data.cbegin(); }
+    auto cend() const noexcept { return m_data.cend(); }
     void resize(size_t n) { m_data.resize(n); }
     void clear() noexcept { m_data.clear(); }
     explicit operator bool() const { return !m_data.empty(); }
+    // samples [start, end) of the buffer, not owned
+    SampleBufferView<SampleType> view(size_t start, size_t end) const {
+        assert(start < m_data.size() && end > start && end <= m_data.size());
+        return SampleBufferView<SampleType>(m_data.data() + start, m_data.data() + end);
+    }
 
   private:
+    size_t slot(int i) const {
+        if constexpr (Circular) {
+            const long long n = static_cast<long long>(m_data.size());
+            return static_cast<size_t>(((static_cast<long long>(i) % n) + n) % n);  // (size + idx) % size for any idx
+        } else {
+            return static_cast<size_t>(i);
+        }
+    }
     std::vector<SampleType> m_data;
 };
-template <typename T>
-using Signal = SampleBuffer<T>;
-template <typename T>
-using Kernel = SampleBuffer<T>;
+template <typename SampleType, size_t Capacity>
+using CircularBuffer = SampleBuffer<SampleType, true, Capacity>;
+template <typename T, bool Circular = false>
+using Signal = SampleBuffer<T, Circular>;
+template <typename T, bool Circular = false>
+using Kernel = SampleBuffer<T, Circular>;
 
 // ---- FFT (fft.h) ------------------------------------------------------------------------------
 enum class FFTType { FORWARD, INVERSE };  // fft.h:9; FORWARD = e^{+i 2 pi k n / N}, nothing normalises

@@ -158,18 +158,27 @@ int run(const std::string &dir) {
         dump(dir + "/iir_ls.f32", ys.data(), ys.size());
         // the audio-callback form: 256-frame blocks into a ring that wraps (coefficients.h:132-170,197-206)
         {
-            struct Ring {  // the part of CircularBuffer<float, 512> the overload touches
-                std::vector<float> slots = std::vector<float>(512);
-                float &operator[](int i) { return slots[static_cast<size_t>(i) % slots.size()]; }
-            } ring;
+            CircularBuffer<float, 512> ring;  // sample_buffer.h:175-176: born with 512 slots, operator[] wraps
+            if (ring.size() != 512) throw std::runtime_error("CircularBuffer<float, 512> must hold 512 slots");
+            ring[-1] = 7.0f;  // (size + idx) % size, sample_buffer.h:67-83
+            if (ring[511] != 7.0f || ring[1023] != 7.0f) throw std::runtime_error("circular index does not wrap");
             auto streaming = recursive::lowPassFilter<4>(0.1);
             std::vector<float> collected;
             for (size_t at = 0; at < x.size(); at += 256) {
                 const size_t len = std::min<size_t>(256, x.size() - at);
                 SampleBuffer<float> block(x.begin() + at, x.begin() + at + len);
                 streaming(block, ring);
-                collected.insert(collected.end(), ring.slots.begin(), ring.slots.begin() + len);
+                collected.insert(collected.end(), ring.begin(), ring.begin() + static_cast<std::ptrdiff_t>(len));
             }
+            // the rest of the container: add(buffer) appends elements, view() is a window, Signal / Kernel aliases
+            Signal<float> grown;
+            grown.add(1.0f);
+            grown.add(SampleBuffer<float>(3, 2.0f));
+            const auto win = grown.view(1, 4);
+            if (grown.size() != 4 || win.size() != 3 || win[0] != 2.0f || win[2] != 2.0f || !grown)
+                throw std::runtime_error("SampleBuffer::add / view");
+            Kernel<double> none;
+            if (none) throw std::runtime_error("an empty buffer must convert to false");
             dump(dir + "/iir_ring.f32", collected.data(), collected.size());
         }
         // batched rows through the same coefficients
