@@ -369,7 +369,8 @@ def test_direct_short_channels(ops, dev, orc, n, ntaps, channels):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("channels,n,ntaps", [(6, 40000, 511), (3, 65536, 255), (2, 100000, 1025), (5, 30720, 64),
-                                              (1, 3584 * 9 + 4096, 511), (4, 20480, 2049), (7, 12288, 300), (2, 50000, 1800)])
+                                              (1, 3584 * 9 + 4096, 511), (4, 20480, 2049), (7, 12288, 300), (2, 50000, 1800),
+                                              (3, 40000, 700), (2, 60000, 1200), (2, 60000, 1500), (2, 60000, 1700)])
 def test_overlap_save_wave_kernel(ops, dev, orc, channels, n, ntaps, monkeypatch):
     """The one-wave-per-block-pair kernel (long signals by default) forced onto small inputs: against the oracle and
     against the workgroup kernel, incl. pairs that straddle channels, first / last blocks (edge pairs) and hops
