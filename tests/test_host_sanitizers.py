@@ -29,6 +29,10 @@ def _run(path, *args, env=None, timeout=600):
     e = dict(os.environ, **(env or {}))
     e.pop("LD_PRELOAD", None)  # a preloaded library in front of the sanitizer runtime makes ASan refuse to start
     p = subprocess.run([path, *args], capture_output=True, text=True, timeout=timeout, env=e)
+    # a sanitizer runtime that cannot start on this kernel (address-space layout it does not know) is not a finding
+    for msg in ("unexpected memory mapping", "Shadow memory range interleaves", "ReserveShadowMemoryRange failed"):
+        if p.returncode != 0 and msg in p.stderr and "host hammer" not in p.stdout:
+            pytest.skip(f"sanitizer runtime cannot start here: {msg}")
     assert p.returncode == 0, (p.stdout[-3000:], p.stderr[-6000:])
     return p.stdout
 
