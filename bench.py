@@ -22,6 +22,9 @@ scaling, no data-path collective) and `value` = samples all ranks processed / ma
                never the thing measured; outside the timed region; rank 0 at N=1 only, skipped by --no-cpu-baseline).
 `cold`         default run only: the headline FFT measured FIRST in the fresh process (chip still ramping, DESIGN.md
                4.1) beside `value`, which is measured last at sustained clocks.
+`dist`         default run at N > 1: the distributed transform (C5) checks itself on the ranks of this run -- parity at 2^24
+               points, local / exchange / serial / pipelined times -- after everything else has been measured, in child
+               processes of its own; a failure there shows as `dist.error`, the rest of the line is unaffected.
 `cpu_baseline` the reference's own code (oracle/_ref, kind "reference") if that library
                travelled with the tree, else the oracle restatement (kind "port"), single
                thread (the reference is single-threaded), on a bounded sample of the workload.
@@ -56,6 +59,11 @@ def parse():
                     help="fft_dist only: all_to_all_single between the plan's phases, or dsp_gpu_fft_dist's own RCCL exchange")
     ap.add_argument("--dist-serial", action="store_true",
                     help="fft_dist with --dist-exchange rccl: the unpipelined schedule (A/B partner of the default)")
+    ap.add_argument("--no-dist-report", action="store_true",
+                    help="default fft run at N > 1: skip the `dist` section (the distributed transform's self-check)")
+    ap.add_argument("--dist-budget", type=float, default=90.0,
+                    help="seconds the `dist` section of the default N > 1 run may take before the line goes out without it")
+    ap.add_argument("--dist-child", action="store_true", help=argparse.SUPPRESS)  # the `dist` section's own process
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true",
                     help="default fft run only: skip the FIR / IIR / moving-average workloads reported under `secondary`")
@@ -329,9 +337,10 @@ def make_fft_dist(torch, dev, world, rank, exchange, serial=False):
         xl = torch.view_as_complex(torch.randn(n_loc, 2, device=dev, generator=gg))
         got = transform(xl, lg)
         if world > 1:
-            parts = [torch.empty_like(xl) for _ in range(world)]
-            dist.all_gather(parts, xl)
-            full = torch.cat(parts)
+            mine = torch.view_as_real(xl).contiguous()
+            parts = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(parts, mine)
+            full = torch.view_as_complex(torch.cat(parts))
         else:
             full = xl
         want = ops.fft0(full.reshape(1, -1), False).reshape(-1)[rank * n_loc:(rank + 1) * n_loc]
@@ -361,6 +370,15 @@ def make_fft_dist(torch, dev, world, rank, exchange, serial=False):
             rep["overlap_fraction"] = (rep["serial_ms"] - rep["pipelined_ms"]) / ex if ex > 0 else None
             rep["overlap_what"] = ("(serial - pipelined) / (serial - local passes alone): the share of the exchange time the "
                                    "pipelined schedule hides; scripts/dist_overlap.py computes the same from a kernel trace")
+            rep["gsamples_per_s"] = {"serial": (1 << log2n) / rep["serial_ms"] / 1e6,
+                                     "pipelined": (1 << log2n) / rep["pipelined_ms"] / 1e6,
+                                     "what": f"one 2^{log2n}-point transform over {world} rank(s), this rank's event times"}
+            # the other exchange route (torch.distributed between the plan's phases) against the same answer
+            if dist.is_initialized():
+                got_t = dist_fft.fft_dist(xl, lg, False)
+                err_t = float((torch.linalg.vector_norm(got_t - want) / torch.linalg.vector_norm(want)).item())
+                rep["parity_2p24_torch_exchange"] = {"rel_l2_vs_single_gpu": err_t, "tol": 2e-5 * lg,
+                                                     "ok": bool(err_t <= 2e-5 * lg)}
         else:
             rep["overlap_fraction"] = 0.0
             rep["overlap_what"] = "phases and all_to_all_single alternate on one stream: nothing overlaps by construction"
@@ -471,6 +489,13 @@ def _cpu_sample(workload, seconds, seed):
 
 def main():
     args = parse()
+    if args.dist_child:
+        return dist_child_main(args)
+    # stdout carries THE line and nothing else: RCCL prints a version banner to file descriptor 1 when a communicator is
+    # made, so everything but the line goes to stderr from here on
+    sys.stdout.flush()
+    line_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
 
@@ -628,42 +653,142 @@ def main():
             resolve_parity(rec)
     if cold_rec is not None and args.headline_first:
         main_rec, cold_rec = dict(cold_rec, parity=main_rec.get("parity")), main_rec
-    if rank == 0:
-        line = {"metric": main_rec["metric"], "value": main_rec["value"], "unit": main_rec["unit"], "n_gpus": world,
-                "steps": args.steps, "warmup": args.warmup, "ms_per_step": main_rec["ms_per_step"],
-                "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": main_rec["dtype"],
-                "data": "synthetic", "config": main_rec["config"], "roofline": main_rec["roofline"],
-                "step_ms": main_rec["step_ms"]}
-        for k in ("parity", "dist", "per_rank_units"):
-            if main_rec.get(k) is not None:
-                line[k] = main_rec[k]
-        if rccl_ranks is not None:
-            line["rccl_ranks"] = rccl_ranks
-        if cold_rec is not None:
-            line["cold" if not args.headline_first else "sustained"] = {
-                "value": cold_rec["value"], "ms_per_step": cold_rec["ms_per_step"], "launch_ms": cold_rec["roofline"]["launch_ms"],
-                "frac": cold_rec["roofline"]["frac"], "step_ms": cold_rec["step_ms"],
-                "what": ("the same K steps measured first in the fresh process, before the secondary workloads"
-                         if not args.headline_first else "the same K steps measured last, after the secondary workloads")}
-        cpu = world == 1 and not args.no_cpu_baseline and args.workload not in ("fft_32k", "fft_real_64k", "fft_f64")
-        if cpu:
-            line["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_seconds)
-            if args.cpu_threads > 1:  # reported beside it, never the target (the roofline fraction is)
-                line["cpu_baseline_all_cores"] = cpu_baseline(args.workload, args.cpu_seconds / 2, args.cpu_threads)
-            if args.workload == "fft":
-                line["cpu_baseline_f32"] = cpu_baseline("fft_f32", args.cpu_seconds / 4)
-        if secondary:
-            line["secondary"] = []
-            for w, rec in secondary:
-                rec = dict(rec, workload=w, steps=args.steps, warmup=args.warmup)
-                if cpu:
-                    rec["cpu_baseline"] = cpu_baseline(w, min(args.cpu_seconds / 4, 1.5))
-                    if args.cpu_threads > 1:
-                        rec["cpu_baseline_all_cores"] = cpu_baseline(w, min(args.cpu_seconds / 6, 1.0), args.cpu_threads)
-                line["secondary"].append(rec)
-        print(json.dumps(line), flush=True)
+
+    def emit(dist_rec=None):
+        """Rank 0 prints THE line."""
+        if rank == 0:
+            line = {"metric": main_rec["metric"], "value": main_rec["value"], "unit": main_rec["unit"], "n_gpus": world,
+                    "steps": args.steps, "warmup": args.warmup, "ms_per_step": main_rec["ms_per_step"],
+                    "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": main_rec["dtype"],
+                    "data": "synthetic", "config": main_rec["config"], "roofline": main_rec["roofline"],
+                    "step_ms": main_rec["step_ms"]}
+            for k in ("parity", "dist", "per_rank_units"):
+                if main_rec.get(k) is not None:
+                    line[k] = main_rec[k]
+            if dist_rec is not None:
+                line["dist"] = dist_rec
+            if rccl_ranks is not None:
+                line["rccl_ranks"] = rccl_ranks
+            if cold_rec is not None:
+                line["cold" if not args.headline_first else "sustained"] = {
+                    "value": cold_rec["value"], "ms_per_step": cold_rec["ms_per_step"], "launch_ms": cold_rec["roofline"]["launch_ms"],
+                    "frac": cold_rec["roofline"]["frac"], "step_ms": cold_rec["step_ms"],
+                    "what": ("the same K steps measured first in the fresh process, before the secondary workloads"
+                             if not args.headline_first else "the same K steps measured last, after the secondary workloads")}
+            cpu = world == 1 and not args.no_cpu_baseline and args.workload not in ("fft_32k", "fft_real_64k", "fft_f64")
+            if cpu:
+                line["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_seconds)
+                if args.cpu_threads > 1:  # reported beside it, never the target (the roofline fraction is)
+                    line["cpu_baseline_all_cores"] = cpu_baseline(args.workload, args.cpu_seconds / 2, args.cpu_threads)
+                if args.workload == "fft":
+                    line["cpu_baseline_f32"] = cpu_baseline("fft_f32", args.cpu_seconds / 4)
+            if secondary:
+                line["secondary"] = []
+                for w, rec in secondary:
+                    rec = dict(rec, workload=w, steps=args.steps, warmup=args.warmup)
+                    if cpu:
+                        rec["cpu_baseline"] = cpu_baseline(w, min(args.cpu_seconds / 4, 1.5))
+                        if args.cpu_threads > 1:
+                            rec["cpu_baseline_all_cores"] = cpu_baseline(w, min(args.cpu_seconds / 6, 1.0), args.cpu_threads)
+                    line["secondary"].append(rec)
+            sys.stdout.flush()
+            with os.fdopen(line_fd, "w") as out:
+                out.write(json.dumps(line) + "\n")
+
+    # Default run under torch.distributed: the line also carries `dist`, the distributed transform (C5, the one path
+    # with a real exchange step) checking itself on the ranks of this very run.  It runs AFTER everything above has been
+    # measured and in child processes of its own (one per rank, a process group of their own), so that a failure, a
+    # hang or a crash in it costs this section and nothing else: the line then goes out with `dist.error`.
+    dist_rec = None
+    if use_dist and args.workload == "fft" and not args.no_dist_report and not args.no_secondary:
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        dist_rec = run_dist_children(dist, rank, world, local_rank, args.dist_budget)
+    emit(dist_rec)
     if use_dist:
         dist.destroy_process_group()
+
+
+def run_dist_children(dist, rank, world, local_rank, budget_s):
+    """One child process per rank runs `bench.py --dist-child`; rank 0's child prints the report as JSON."""
+    import socket
+    import subprocess
+    import tempfile
+    box = [None]
+    if rank == 0:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            box[0] = sk.getsockname()[1]
+    if world > 1:
+        dist.broadcast_object_list(box, src=0)
+    env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_")}
+    env.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(box[0]), "RANK": str(rank), "WORLD_SIZE": str(world),
+                "LOCAL_RANK": str(local_rank)})
+    with tempfile.TemporaryFile() as err:
+        child = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--dist-child", "--gpus", str(world),
+                                  "--dist-budget", str(budget_s)], env=env, stdout=subprocess.PIPE, stderr=err, cwd=ROOT)
+        try:
+            out, _ = child.communicate(timeout=budget_s + 15.0)
+        except subprocess.TimeoutExpired:
+            child.kill()
+            out, _ = child.communicate()
+            return {"error": f"rank {rank}'s child did not finish within {budget_s + 15.0:.0f} s"}
+        if rank != 0:
+            return None
+        try:
+            return json.loads(out.decode().strip().splitlines()[-1])
+        except Exception:  # no report: say why, with the end of the child's stderr
+            err.seek(0)
+            tail = err.read().decode(errors="replace")[-600:]
+            return {"error": f"rank 0's child ended with status {child.returncode} and no report", "stderr_tail": tail}
+
+
+def dist_child_main(args):
+    """`--dist-child`: the `dist` section of the default N > 1 line (run_dist_children), in a process group of its own."""
+    import threading
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ["WORLD_SIZE"])
+    rank = int(os.environ["RANK"])
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    rep = {}
+
+    def out_of_time():  # a rank that waits for a peer that died: say so and leave before the parent has to kill us
+        if rank == 0:
+            print(json.dumps(dict(rep, error=f"the dist section did not finish within {args.dist_budget:.0f} s")), flush=True)
+        os._exit(3)
+
+    timer = threading.Timer(args.dist_budget, out_of_time)
+    timer.daemon = True
+    timer.start()
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist.init_process_group("nccl", device_id=dev)
+    ones = torch.ones(1, device=dev)
+    dist.all_reduce(ones)
+    rep["ranks"] = int(ones.item())
+    rehearse = os.environ.get("DSP_BENCH_DIST_CHILD_TEST")  # scripts/bench_rehearsal.sh: the parent's line must survive both
+    if rehearse == "crash":
+        os.abort()
+    if rehearse == "hang":
+        time.sleep(1e6)
+    try:
+        _, _, meta = make_fft_dist(torch, dev, world, rank, "rccl")
+        rep.update(meta["dist_report"]())
+        rep["config"] = meta["config"]
+        torch.cuda.synchronize()
+    except Exception as e:  # reported, not raised: the parent's line says what went wrong
+        rep["error"] = f"rank {rank}: {type(e).__name__}: {e}"[:600]
+    ok = "error" not in rep and rep.get("parity_2p24", {}).get("ok", False)
+    oks = torch.tensor([1.0 if ok else 0.0], device=dev)
+    dist.all_reduce(oks)  # every rank, whatever happened to it (a peer stuck elsewhere: the timer above)
+    rep["ranks_with_parity_ok"] = int(oks.item())
+    timer.cancel()
+    if rank == 0:
+        print(json.dumps(rep), flush=True)
+    sys.stdout.flush()
+    os._exit(0)  # no teardown of communicators that may be half-dead
 
 
 def measured_traffic(workload):
