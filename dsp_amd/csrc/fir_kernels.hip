@@ -735,10 +735,14 @@ __global__ __launch_bounds__(kOsWave2Threads) void fir_os_wave2_kernel(
     // (channel, block) of the first block of the pair, stepped by two blocks per pair
     size_t ch = (2 * tile0) / blocks_per_channel;
     unsigned blk = static_cast<unsigned>((2 * tile0) % blocks_per_channel);
-    float keep[4 * I0];  // rows 64 - 4 I0 .. 63 of the last pair's second block = rows 0 .. 4 I0 - 1 of the next pair's first
+    // rows 64 - 4 I0 .. 63 of the last pair's second block = rows 0 .. 4 I0 - 1 of the next pair's first: kept in registers
+    // while they fit (hops from 2560 samples up; below that 28 or 32 more registers would spill, and the rows are read again)
+    constexpr bool KEEP = I0 <= 6;
+    constexpr int kKeep = KEEP ? 4 * I0 : 1;
+    float keep[kKeep];
     bool have_keep = false;
 #pragma unroll
-    for (int m = 0; m < 4 * I0; ++m) keep[m] = 0.0f;
+    for (int m = 0; m < kKeep; ++m) keep[m] = 0.0f;
     for (unsigned pp = 0; pp < run_len; ++pp) {
         const size_t tile = tile0 + pp;
         if (tile >= tiles) break;
@@ -757,9 +761,9 @@ __global__ __launch_bounds__(kOsWave2Threads) void fir_os_wave2_kernel(
         }
         const float *pa = x + ch_a * n + static_cast<size_t>(in_a) + lane, *pb = pa + L;
         c32 r[P];
-        if (have_keep) {
+        if (KEEP && have_keep) {
 #pragma unroll
-            for (int m = 0; m < 4 * I0; ++m) r[m].x = keep[m];
+            for (int m = 0; m < kKeep; ++m) r[m].x = keep[m];
         } else {
 #pragma unroll
             for (int m = 0; m < 4 * I0; ++m) r[m].x = __builtin_nontemporal_load(pa + T * m);
@@ -770,9 +774,11 @@ __global__ __launch_bounds__(kOsWave2Threads) void fir_os_wave2_kernel(
         for (int m = 4 * I0; m < P; ++m) r[m].y = __builtin_nontemporal_load(pb + T * m);
 #pragma unroll
         for (int m = 0; m < 4 * I0; ++m) r[m].y = r[m + P - 4 * I0].x;  // hop = whole rows: block b starts inside block a
+        if constexpr (KEEP) {
 #pragma unroll
-        for (int m = 0; m < 4 * I0; ++m) keep[m] = r[m + P - 4 * I0].y;
-        have_keep = true;
+            for (int m = 0; m < 4 * I0; ++m) keep[m] = r[m + P - 4 * I0].y;
+            have_keep = true;
+        }
 
         fft4096_wave_quad<+1>(r, img, lane);
 #pragma unroll
@@ -1229,7 +1235,7 @@ int launch_os(const float *x, float *y, size_t channels, size_t n, const c32 *d_
         // DSP_GPU_OS_WAVE_FORM=agpr: round 2's kernel (one wave per SIMD, WIDE transpose, prefetch into AGPRs by hand);
         // default: two waves per SIMD, QUAD transpose, sequential runs (fir_os_wave2_kernel).  Identical bits.
         const char *form = getenv("DSP_GPU_OS_WAVE_FORM");
-        if (!(form && form[0] == 'a') && (kOsN - L) / 256 <= 6) {  // (hops below 2560: the kept rows would spill registers)
+        if (!(form && form[0] == 'a')) {
             // runs: whole rounds of one 8-wave workgroup per CU (a last round that fills a quarter of the chip costs as much
             // as a full one), about 32 pairs to a run
             const size_t per_round = static_cast<size_t>(cus) * kOsWave2Waves;

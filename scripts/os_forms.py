@@ -15,7 +15,7 @@ if len(sys.argv) > 1:
     dev = torch.device("cuda:0")
     x = torch.randn(1024, 1 << 20, device=dev)
     y = torch.empty_like(x)
-    for ntaps in (127, 255, 511, 767, 1025, 1535):
+    for ntaps in (127, 255, 511, 767, 1025, 1535, 1793, 2049):
         h = np.random.default_rng(ntaps).standard_normal(ntaps) / ntaps ** 0.5
         for _ in range(5):
             ops.convolve(x, h, "overlap_save", out=y)
