@@ -819,6 +819,26 @@ DSP_DEV double shfl_up_f64(double v, int delta) {
     hi = __shfl_up(hi, delta, 64);
     return __hiloint2double(hi, lo);
 }
+// Inclusive prefix sum of a double over the 64 lanes by data-parallel-primitive moves, no LDS round trip: Kogge-Stone inside
+// every row of 16 lanes (row_shr 1, 2, 4, 8; lanes shifted in from outside the row read 0), then lane 15 of rows 0 and 2
+// into rows 1 and 3 (row_bcast15, row mask 0xa) and lane 31 into rows 2 and 3 (row_bcast31, row mask 0xc).  Three vector
+// instructions a step against the eight (two of them LDS permutes with their latency) of a shuffle-based step.
+template <int CTRL, int ROW_MASK>
+DSP_DEV double dpp_move_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+DSP_DEV double wave_inclusive_sum_f64(double v) {
+    v += dpp_move_f64<0x111, 0xf>(v);
+    v += dpp_move_f64<0x112, 0xf>(v);
+    v += dpp_move_f64<0x114, 0xf>(v);
+    v += dpp_move_f64<0x118, 0xf>(v);
+    v += dpp_move_f64<0x142, 0xa>(v);
+    v += dpp_move_f64<0x143, 0xc>(v);
+    return v;
+}
 // 16 pad BYTES per 16 samples (4 floats / 2 doubles): conflict-free ds_read_b128 for consecutive lanes on consecutive chunks
 template <typename T>
 DSP_DEV int ma_pad(int i) { return i + ((i >> 4) * Smp<T>::kVec); }
@@ -841,7 +861,7 @@ DSP_DEV int ma_pad(int i) { return i + ((i >> 4) * Smp<T>::kVec); }
 template <bool ALIGNED, int kMaPer, typename T = float>
 __global__ __launch_bounds__(kThreads) void moving_average_kernel(const T *__restrict__ x, T *__restrict__ y,
                                                                   size_t n, int npoints, int span, int cpt, int skip_lo,
-                                                                  int skip_n) {
+                                                                  int skip_n, double inv) {  // inv = 1.0 / npoints (host)
     using V = typename Smp<T>::vec;
     constexpr int kVec = Smp<T>::kVec;
     constexpr int kMaTile = kThreads * kMaPer;
@@ -913,10 +933,11 @@ __global__ __launch_bounds__(kThreads) void moving_average_kernel(const T *__res
     // round k: thread t owns chunk t + 256*k (consecutive lanes on consecutive chunks: the 20-dword lane
     // stride keeps the 16-byte LDS accesses conflict-free).  In-chunk exclusive prefixes (sample type, in place),
     // then a block-wide exclusive scan of the chunk totals in double, rounds chained through `base`.
-    const int lane = tid & 63, wave = tid >> 6;
-    double base = 0.0;
-    for (int k = 0; k < cpt; ++k) {
-        const int c = tid + kThreads * k;
+    // Rounds go in PAIRS behind one barrier (C3: 289 chunks = one full round and one of 33 chunks, whose scan only
+    // wave 0 runs): the two wave scans are independent chains, and a wave without a chunk in a round skips its scan.
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    auto chunk_prefix = [&](int c) -> double {  // exclusive prefixes inside chunk c, in place; returns the chunk's sum
         T run = T(0);
         if (c < chunks) {
 #pragma unroll
@@ -932,39 +953,61 @@ __global__ __launch_bounds__(kThreads) void moving_average_kernel(const T *__res
                 *p = e;
             }
         }
-        const double mine = static_cast<double>(run);
-        double incl = mine;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const double o = shfl_up_f64(incl, d);
-            if (lane >= d) incl += o;
+        return static_cast<double>(run);
+    };
+    double base = 0.0;
+    for (int k = 0; k < cpt; k += 2) {
+        const int c0 = tid + kThreads * k, c1 = c0 + kThreads;
+        const double m0 = chunk_prefix(c0), m1 = chunk_prefix(c1);
+        double i0 = m0, i1 = m1;
+        if (kThreads * k + 64 * wave < chunks) i0 = wave_inclusive_sum_f64(m0);        // (wave-uniform)
+        if (kThreads * (k + 1) + 64 * wave < chunks) i1 = wave_inclusive_sum_f64(m1);  // (wave-uniform)
+        if (lane == 63) {
+            wave_tot[4 * k + wave] = i0;
+            wave_tot[4 * k + 4 + wave] = i1;
         }
-        if (lane == 63) wave_tot[4 * k + wave] = incl;
         __syncthreads();
-        double running = base + (incl - mine);
-        for (int w = 0; w < wave; ++w) running += wave_tot[4 * k + w];
-        if (c < chunks) pc[c] = running;  // exclusive prefix of the chunk sums
-        base += wave_tot[4 * k] + wave_tot[4 * k + 1] + wave_tot[4 * k + 2] + wave_tot[4 * k + 3];
+        double t[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t[q] = wave_tot[4 * k + q];
+        double r0 = base + (i0 - m0);  // exclusive prefix of the chunk sums: rounds before, waves before, lanes before
+        if (wave > 0) r0 += t[0];
+        if (wave > 1) r0 += t[1];
+        if (wave > 2) r0 += t[2];
+        if (c0 < chunks) pc[c0] = r0;
+        base += t[0] + t[1] + t[2] + t[3];
+        double r1 = base + (i1 - m1);
+        if (wave > 0) r1 += t[4];
+        if (wave > 1) r1 += t[5];
+        if (wave > 2) r1 += t[6];
+        if (c1 < chunks) pc[c1] = r1;
+        base += t[4] + t[5] + t[6] + t[7];
     }
     __syncthreads();
 
-    const double inv = 1.0 / static_cast<double>(npoints);
     const double dcorr = static_cast<double>(corr);
     const long long hi = (nn - mid > mid + 1) ? nn - mid : mid + 1;  // out[mid] is always written (filter.h:93)
     // double samples: divide as the reference does (sum / M, filter.h:93,97) rather than multiply by the reciprocal
+    const double ncorr_inv = -dcorr * inv;
     auto mean = [&](double sum) -> T {
         if constexpr (sizeof(T) == 8) return (sum - dcorr) / static_cast<double>(npoints);
-        else return static_cast<T>((sum - dcorr) * inv);
+        else return static_cast<T>(fma(sum, inv, ncorr_inv));  // (sum - corr) / P in one operation; corr = 0 for odd P
     };
     if (out0 >= mid && out0 + kMaTile <= hi) {  // interior tile: every output has its full window
-        T *yt = yc + out0;
+        // Output i of a thread sits kThreads = 16 chunks further on than output i - 1, so all four LDS addresses move by
+        // constants: they are computed once and the loop body is reads at immediate offsets plus the arithmetic (left to
+        // the compiler the padding's shift-and-add was redone for every output: 26 vector instructions per output against
+        // 8, in a kernel whose vector ALU was 87 % busy -- profiles/r03_mavg_pmc.txt).
+        T *yt = yc + out0 + tid;
+        const int lo0 = tid + shift, up0 = lo0 + window;  // window of output tid = staged samples [lo0, up0)
+        const T *plo = xs + ma_pad<T>(lo0), *pup = xs + ma_pad<T>(up0);
+        const double *qlo = pc + (lo0 >> 4), *qup = pc + (up0 >> 4);
+        constexpr int kRow = kThreads + (kThreads >> 4) * kVec;  // ma_pad(u + kThreads) - ma_pad(u)
 #pragma unroll
         for (int i = 0; i < kMaPer; ++i) {
-            const int jrel = kThreads * i + tid;
-            const int lo = jrel + shift, up = lo + window;  // window = staged samples [lo, up)
-            const double sum = (pc[up >> 4] - pc[lo >> 4]) +
-                               (static_cast<double>(xs[ma_pad<T>(up)]) - static_cast<double>(xs[ma_pad<T>(lo)]));
-            __builtin_nontemporal_store(mean(sum), yt + jrel);
+            const double sum = (qup[(kThreads >> 4) * i] - qlo[(kThreads >> 4) * i]) +
+                               (static_cast<double>(pup[kRow * i]) - static_cast<double>(plo[kRow * i]));
+            __builtin_nontemporal_store(mean(sum), yt + kThreads * i);
         }
         return;
     }
@@ -1006,7 +1049,7 @@ __global__ __launch_bounds__(kThreads) void moving_average_seq_kernel(const T *_
     T *xs = reinterpret_cast<T *>(smem_raw);
     double *pc = reinterpret_cast<double *>(xs + ma_pad<T>(span));  // chunks + 1 entries: pc[chunks] = total of the span
     double *wave_tot = pc + chunks + 1;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const size_t ch = blockIdx.y;
     const int t0 = tile_lo + static_cast<int>(blockIdx.x) * run;
     const int count = min(run, tile_lo + tile_n - t0);
@@ -1043,35 +1086,32 @@ __global__ __launch_bounds__(kThreads) void moving_average_seq_kernel(const T *_
             }
             const double mine = static_cast<double>(run_sum);
             double incl = mine;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const double o = shfl_up_f64(incl, d);
-                if (lane >= d) incl += o;
-            }
+            if (c_first + kThreads * k + 64 * wave < chunks) incl = wave_inclusive_sum_f64(mine);  // (wave-uniform)
             if (lane == 63) wave_tot[4 * k + wave] = incl;
             __syncthreads();
+            const double t0 = wave_tot[4 * k], t1 = wave_tot[4 * k + 1], t2 = wave_tot[4 * k + 2], t3 = wave_tot[4 * k + 3];
             double running = base + (incl - mine);
-            for (int w = 0; w < wave; ++w) running += wave_tot[4 * k + w];
+            if (wave > 0) running += t0;
+            if (wave > 1) running += t1;
+            if (wave > 2) running += t2;
             if (c < chunks) pc[c] = running;
-            base += wave_tot[4 * k] + wave_tot[4 * k + 1] + wave_tot[4 * k + 2] + wave_tot[4 * k + 3];
+            base += t0 + t1 + t2 + t3;
         }
         if (tid == 0) pc[chunks] = base;
         return base;
     };
-    auto emit = [&](long long out0) {
-        T *yt = yc + out0;
-        // (opaque per call: otherwise the compiler hoists the 64 LDS addresses of this loop out of the tile loop and the
-        // kernel needs 132 registers instead of ~40 -- three workgroups per CU instead of six)
-        int sh = shift;
-        asm volatile("" : "+v"(sh));
+    auto emit = [&](long long out0) {  // as moving_average_kernel's interior tiles: four LDS addresses, the rest immediates
+        T *yt = yc + out0 + tid;
+        const int lo0 = tid + shift, up0 = lo0 + window;
+        const T *plo = xs + ma_pad<T>(lo0), *pup = xs + ma_pad<T>(up0);
+        const double *qlo = pc + (lo0 >> 4), *qup = pc + (up0 >> 4);
+        constexpr int kRow = kThreads + (kThreads >> 4) * kVec;
 #pragma unroll
         for (int i = 0; i < kMaPerMax; ++i) {
-            const int jrel = kThreads * i + tid;
-            const int lo = jrel + sh, up = lo + window;
-            const double sum = (pc[up >> 4] - pc[lo >> 4]) +
-                               (static_cast<double>(xs[ma_pad<T>(up)]) - static_cast<double>(xs[ma_pad<T>(lo)]));
-            if constexpr (sizeof(T) == 8) __builtin_nontemporal_store((sum - dcorr) / static_cast<double>(npoints), yt + jrel);
-            else __builtin_nontemporal_store(static_cast<T>((sum - dcorr) * inv), yt + jrel);
+            const double sum = (qup[(kThreads >> 4) * i] - qlo[(kThreads >> 4) * i]) +
+                               (static_cast<double>(pup[kRow * i]) - static_cast<double>(plo[kRow * i]));
+            if constexpr (sizeof(T) == 8) __builtin_nontemporal_store((sum - dcorr) / static_cast<double>(npoints), yt + kThreads * i);
+            else __builtin_nontemporal_store(static_cast<T>(fma(sum, inv, -dcorr * inv)), yt + kThreads * i);
         }
     };
     const T *newp = xc + seg0 + 16 * carried + tid * kVec;  // this thread's first new sample of tile 0 (as if it were a later tile)
@@ -1343,15 +1383,19 @@ int launch_moving_average_t(const T *x, T *y, size_t channels, size_t n, int npo
     // otherwise stage and scan mostly padding)
     int per = kMaPerMax;
     while (per > 1 && static_cast<size_t>(kThreads) * (per / 2) >= n) per /= 2;
+    if (const char *e = getenv("DSP_GPU_MAVG_PER"))  // A/B runs: outputs per thread (1, 2, 4, 8, 16)
+        if (atoi(e) >= 1 && atoi(e) <= per) per = atoi(e);
     const int tile = kThreads * per;
     // staged samples: tile + window, + kVec - 1 for the aligned start, + 1 so index `up` of the last output exists
     const int span = ((tile + window + kVec + 15) / 16) * 16;
     const int chunks = span / 16;
     const int cpt = (chunks + kThreads - 1) / kThreads;
-    const size_t lds_bytes = static_cast<size_t>(span + (span / 16) * kVec) * sizeof(T) + static_cast<size_t>(chunks + 4 * cpt) * sizeof(double);
+    const size_t lds_bytes = static_cast<size_t>(span + (span / 16) * kVec) * sizeof(T) + static_cast<size_t>(chunks + 4 * ((cpt + 1) & ~1)) * sizeof(double) +
+                             [] { const char *e = getenv("DSP_GPU_MAVG_LDS_PAD"); return e ? static_cast<size_t>(atoi(e)) : size_t(0); }();  // A/B runs: fewer workgroups per CU
     const size_t blocks = (n + tile - 1) / tile;
+    const double inv = 1.0 / static_cast<double>(npoints);
     const bool aligned = (n % kVec == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0);
-    void (*kern)(const T *, T *, size_t, int, int, int, int, int) = nullptr;
+    void (*kern)(const T *, T *, size_t, int, int, int, int, int, double) = nullptr;
 #define DSPGPU_MA_PICK(PER) kern = aligned ? moving_average_kernel<true, PER, T> : moving_average_kernel<false, PER, T>
     switch (per) {
     case 1: DSPGPU_MA_PICK(1); break;
@@ -1387,11 +1431,11 @@ int launch_moving_average_t(const T *x, T *y, size_t channels, size_t n, int npo
             hipLaunchKernelGGL(kseq, dim3(runs, channels), dim3(kThreads), lds_seq, s, x, y, n, npoints, span, static_cast<int>(lo), tile_n, run);
             if (int rc = check_launch("moving_average_seq_kernel")) return rc;
             const size_t edge = blocks - static_cast<size_t>(tile_n);
-            if (edge) hipLaunchKernelGGL(kern, dim3(edge, channels), dim3(kThreads), lds_bytes, s, x, y, n, npoints, span, cpt, static_cast<int>(lo), tile_n);
+            if (edge) hipLaunchKernelGGL(kern, dim3(edge, channels), dim3(kThreads), lds_bytes, s, x, y, n, npoints, span, cpt, static_cast<int>(lo), tile_n, inv);
             return check_launch("moving_average_kernel (edge tiles)");
         }
     }
-    hipLaunchKernelGGL(kern, dim3(blocks, channels), dim3(kThreads), lds_bytes, s, x, y, n, npoints, span, cpt, 0, 0);
+    hipLaunchKernelGGL(kern, dim3(blocks, channels), dim3(kThreads), lds_bytes, s, x, y, n, npoints, span, cpt, 0, 0, inv);
     return check_launch("moving_average_kernel");
 }
 }  // namespace
