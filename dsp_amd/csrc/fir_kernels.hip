@@ -855,13 +855,13 @@ DSP_DEV int ma_pad(int i) { return i + ((i >> 4) * Smp<T>::kVec); }
 // shuffles).  y[j] = (G[j + window] - G[j]) / P with G[u] = chunk_prefix[u >> 4] + in_chunk[u];
 // consecutive lanes take consecutive outputs, so the LDS reads are conflict-free and the global
 // stores coalesced.  Nothing is carried along the signal, hence none of the reference's accumulated
-// drift.  LDS: T xs[ma_pad(span)], double pc[chunks], double wave_tot[4].
+// drift.  LDS: T xs[ma_pad(span)], double pc[chunks], double wave_tot[8 per pair of rounds], double d1[tile / 16 + 1].
 // T = float (BASELINE's type) or double (SampleBuffer<double>, what the reference's own callers filter:
 // eval/moving_average_filter_demo/main.cpp:14).
 template <bool ALIGNED, int kMaPer, typename T = float>
 __global__ __launch_bounds__(kThreads) void moving_average_kernel(const T *__restrict__ x, T *__restrict__ y,
                                                                   size_t n, int npoints, int span, int cpt, int skip_lo,
-                                                                  int skip_n, double inv) {  // inv = 1.0 / npoints (host)
+                                                                  int skip_n, double inv, int ld_mode, int halo) {  // inv = 1.0 / npoints (host)
     using V = typename Smp<T>::vec;
     constexpr int kVec = Smp<T>::kVec;
     constexpr int kMaTile = kThreads * kMaPer;
@@ -899,7 +899,11 @@ __global__ __launch_bounds__(kThreads) void moving_average_kernel(const T *__res
             for (; u0 + 3 * kStep < span; u0 += 4 * kStep) {
                 V v[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = load_stream<T>(xc + seg0 + u0 + i * kStep);
+                for (int i = 0; i < 4; ++i) {
+                    const int u = u0 + i * kStep;
+                    const bool cached = ld_mode == 2 || (ld_mode == 1 && (u < halo || u >= span - halo));
+                    v[i] = cached ? *reinterpret_cast<const V *>(xc + seg0 + u) : load_stream<T>(xc + seg0 + u);
+                }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) *reinterpret_cast<V *>(xs + ma_pad<T>(u0 + i * kStep)) = v[i];
             }
@@ -998,15 +1002,43 @@ __global__ __launch_bounds__(kThreads) void moving_average_kernel(const T *__res
         // constants: they are computed once and the loop body is reads at immediate offsets plus the arithmetic (left to
         // the compiler the padding's shift-and-add was redone for every output: 26 vector instructions per output against
         // 8, in a kernel whose vector ALU was 87 % busy -- profiles/r03_mavg_pmc.txt).
+        // The chunk-prefix difference pc[up >> 4] - pc[lo >> 4] depends on lo's chunk and on one bit (does lo's offset in
+        // its chunk carry into the next chunk when the window is added): it is formed once per chunk and bit -- D0 over pc
+        // in place, D1 behind it -- so that an output costs three LDS reads instead of four.  LDS is what this kernel
+        // waits for once the vector ALU is out of the way (its index unit was busy 0.78 of the time: 24 bytes read per
+        // 4-byte output); the subtraction is the same one, so are the bits.
+        {
+            const int w16 = window >> 4, n_d = (kMaTile >> 4) + 1;  // lo >> 4 takes the values 0 .. kMaTile / 16
+            double *e1 = wave_tot + 4 * ((cpt + 1) & ~1);
+            double a[2] = {0.0, 0.0}, b0[2] = {0.0, 0.0}, b1[2] = {0.0, 0.0};
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int c = tid + kThreads * r;
+                if (c < n_d) {
+                    a[r] = pc[c];
+                    b0[r] = pc[min(c + w16, chunks - 1)];
+                    b1[r] = pc[min(c + w16 + 1, chunks - 1)];  // (clamped entries belong to combinations no output uses)
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int c = tid + kThreads * r;
+                if (c < n_d) {
+                    pc[c] = b0[r] - a[r];
+                    e1[c] = b1[r] - a[r];
+                }
+            }
+            __syncthreads();
+        }
         T *yt = yc + out0 + tid;
         const int lo0 = tid + shift, up0 = lo0 + window;  // window of output tid = staged samples [lo0, up0)
         const T *plo = xs + ma_pad<T>(lo0), *pup = xs + ma_pad<T>(up0);
-        const double *qlo = pc + (lo0 >> 4), *qup = pc + (up0 >> 4);
+        const double *qd = ((((lo0 & 15) + (window & 15)) >> 4) ? wave_tot + 4 * ((cpt + 1) & ~1) : pc) + (lo0 >> 4);
         constexpr int kRow = kThreads + (kThreads >> 4) * kVec;  // ma_pad(u + kThreads) - ma_pad(u)
 #pragma unroll
         for (int i = 0; i < kMaPer; ++i) {
-            const double sum = (qup[(kThreads >> 4) * i] - qlo[(kThreads >> 4) * i]) +
-                               (static_cast<double>(pup[kRow * i]) - static_cast<double>(plo[kRow * i]));
+            const double sum = qd[(kThreads >> 4) * i] + (static_cast<double>(pup[kRow * i]) - static_cast<double>(plo[kRow * i]));
             __builtin_nontemporal_store(mean(sum), yt + kThreads * i);
         }
         return;
@@ -1390,12 +1422,17 @@ int launch_moving_average_t(const T *x, T *y, size_t channels, size_t n, int npo
     const int span = ((tile + window + kVec + 15) / 16) * 16;
     const int chunks = span / 16;
     const int cpt = (chunks + kThreads - 1) / kThreads;
-    const size_t lds_bytes = static_cast<size_t>(span + (span / 16) * kVec) * sizeof(T) + static_cast<size_t>(chunks + 4 * ((cpt + 1) & ~1)) * sizeof(double) +
+    const size_t lds_bytes = static_cast<size_t>(span + (span / 16) * kVec) * sizeof(T) + static_cast<size_t>(chunks + 4 * ((cpt + 1) & ~1) + tile / 16 + 1) * sizeof(double) +
                              [] { const char *e = getenv("DSP_GPU_MAVG_LDS_PAD"); return e ? static_cast<size_t>(atoi(e)) : size_t(0); }();  // A/B runs: fewer workgroups per CU
     const size_t blocks = (n + tile - 1) / tile;
     const double inv = 1.0 / static_cast<double>(npoints);
+    // loads of an interior tile: the window halo (shared with the neighbouring tiles, which run on the same XCD at about the
+    // same time) through the cache, the rest streaming.  Same speed as all-streaming, 4 % less HBM traffic
+    // (profiles/r03_mavg_sweep.txt).  DSP_GPU_MAVG_LOADS=0 all streaming, 2 all cached (A/B runs).
+    const int ld_mode = [] { const char *e = getenv("DSP_GPU_MAVG_LOADS"); return e ? atoi(e) : 1; }();
+    const int halo = ((window + 15) / 16) * 16 + 16;
     const bool aligned = (n % kVec == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0);
-    void (*kern)(const T *, T *, size_t, int, int, int, int, int, double) = nullptr;
+    void (*kern)(const T *, T *, size_t, int, int, int, int, int, double, int, int) = nullptr;
 #define DSPGPU_MA_PICK(PER) kern = aligned ? moving_average_kernel<true, PER, T> : moving_average_kernel<false, PER, T>
     switch (per) {
     case 1: DSPGPU_MA_PICK(1); break;
@@ -1431,11 +1468,11 @@ int launch_moving_average_t(const T *x, T *y, size_t channels, size_t n, int npo
             hipLaunchKernelGGL(kseq, dim3(runs, channels), dim3(kThreads), lds_seq, s, x, y, n, npoints, span, static_cast<int>(lo), tile_n, run);
             if (int rc = check_launch("moving_average_seq_kernel")) return rc;
             const size_t edge = blocks - static_cast<size_t>(tile_n);
-            if (edge) hipLaunchKernelGGL(kern, dim3(edge, channels), dim3(kThreads), lds_bytes, s, x, y, n, npoints, span, cpt, static_cast<int>(lo), tile_n, inv);
+            if (edge) hipLaunchKernelGGL(kern, dim3(edge, channels), dim3(kThreads), lds_bytes, s, x, y, n, npoints, span, cpt, static_cast<int>(lo), tile_n, inv, ld_mode, halo);
             return check_launch("moving_average_kernel (edge tiles)");
         }
     }
-    hipLaunchKernelGGL(kern, dim3(blocks, channels), dim3(kThreads), lds_bytes, s, x, y, n, npoints, span, cpt, 0, 0, inv);
+    hipLaunchKernelGGL(kern, dim3(blocks, channels), dim3(kThreads), lds_bytes, s, x, y, n, npoints, span, cpt, 0, 0, inv, ld_mode, halo);
     return check_launch("moving_average_kernel");
 }
 }  // namespace
