@@ -54,3 +54,35 @@ for w, key in KERNEL.items():
                       "round": int(ROUND[1:]), "command": f"rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python bench.py --workload {w} --steps 3 --warmup 1 --no-cpu-baseline --no-secondary"}
         print(w, round(traffic[w]["hbm_bytes_per_launch"] / 2**30, 3), "GiB", "rocprof avg ms", traffic[w]["kernel_avg_ms_rocprof"], "bench ms", traffic[w]["bench_launch_ms_hip_events"])
 json.dump(traffic, open(tpath, "w"), indent=1)
+
+# the round-end bench command itself (scripts/profile_default_bench.sh): its line, its kernel stats, every launch in order
+d = os.path.join(SRC, "bench_default")
+if os.path.isdir(d):
+    bj = os.path.join(d, "bench.json")
+    if os.path.exists(bj) and os.path.getsize(bj):
+        shutil.copy(bj, os.path.join(ROOT, "profiles", f"{ROUND}_bench_default.json"))
+    stats = newest(os.path.join(d, "stats", "**", "*kernel_stats.csv"))
+    if stats:
+        shutil.copy(stats[0], os.path.join(ROOT, "profiles", f"{ROUND}_bench_default_kernel_stats.csv"))
+    trace = newest(os.path.join(d, "stats", "**", "*kernel_trace.csv"))
+    if trace:
+        order = ["fft_lds_kernel", "moving_average_kernel", "fir_os_wave2_kernel", "iir_batch_kernel", "iir_scan_kernel"]
+        runs = {k: [] for k in order}
+        for r in csv.DictReader(open(trace[0])):
+            for k in order:
+                if k in r["Kernel_Name"]:
+                    runs[k].append((int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
+        with open(os.path.join(ROOT, "profiles", f"{ROUND}_bench_default_per_launch_us.txt"), "w") as f:
+            f.write("# rocprofv3 --kernel-trace of the default bench command (python bench.py --gpus 1 --steps 20 --warmup 5): duration of every\n"
+                    "# launch of each memory-bound kernel in microseconds, in launch order (5 warm-up + 20 timed + 20 per-step launches per\n"
+                    "# workload; the FFT twice: cold at the start of the process, sustained at its end).  Every workload shows the same shape:\n"
+                    "# its first 3-4 launches are the fastest, launches 5-15 the slowest (the chip's power management answers a new load by\n"
+                    "# dropping the shader clock, profiles/r03_fft_clock_ramp_after_idle.txt), then a slow recovery -- and the driver's 5 warm-up\n"
+                    "# launches are exactly the fast ones.  (scripts/profile_collect.py)\n")
+            for k in order:
+                v = [u for _, u in sorted(runs[k])]
+                med = sorted(v)[len(v) // 2] if v else 0.0
+                v = [u for u in v if u > 0.25 * med]  # (small launches of the same kernel by the parity checks)
+                if v:
+                    f.write(f"{k}   min {min(v):.0f}  launches 6-25 (the timed ones) mean {sum(v[5:25]) / max(len(v[5:25]), 1):.0f}  last 10 mean {sum(v[-10:]) / len(v[-10:]):.0f}\n  "
+                            + " ".join(f"{u:.0f}" for u in v) + "\n")
