@@ -70,11 +70,15 @@ __global__ __launch_bounds__(kThreads) void fft_lds_kernel(const void *__restric
 #pragma unroll
             for (int m = 0; m < kPoints / 2; ++m)
                 v[m] = load_stream_f4(reinterpret_cast<const float *>(src + 2 * (tid + kThreads * m)));
+            // padded(2 tid + 512 m) = padded(2 tid) + 544 m: one address, the rest immediate offsets (e and e + 1 share a
+            // padding group); likewise the gather below and the way out -- left to the compiler every slot got its own
+            // shift-and-add address, ~200 of this kernel's ~640 vector instructions per thread, which is what it runs on while
+            // the shader clock is down
+            c32 *w = lds + padded(2 * tid);
 #pragma unroll
             for (int m = 0; m < kPoints / 2; ++m) {
-                const int e = 2 * (tid + kThreads * m);  // even: e and e + 1 share a padding group
-                lds[padded(e)] = mk(v[m].x, v[m].y);
-                lds[padded(e) + 1] = mk(v[m].z, v[m].w);
+                w[m * (2 * kThreads + 2 * kThreads / 16)] = mk(v[m].x, v[m].y);
+                w[m * (2 * kThreads + 2 * kThreads / 16) + 1] = mk(v[m].z, v[m].w);
             }
         } else {
 #pragma unroll
@@ -84,8 +88,14 @@ __global__ __launch_bounds__(kThreads) void fft_lds_kernel(const void *__restric
             }
         }
         __syncthreads();
+        if constexpr (T % 16 == 0) {
+            const c32 *gsrc = lds + padded(g * N + lt);
 #pragma unroll
-        for (int m = 0; m < kPoints; ++m) r[m] = lds[padded(g * N + lt + T * m)];
+            for (int m = 0; m < kPoints; ++m) r[m] = gsrc[m * (T + T / 16)];
+        } else {
+#pragma unroll
+            for (int m = 0; m < kPoints; ++m) r[m] = lds[padded(g * N + lt + T * m)];
+        }
         __syncthreads();  // the passes reuse the image
     } else if (live) {
         if constexpr (REAL_IN) {
@@ -115,20 +125,30 @@ __global__ __launch_bounds__(kThreads) void fft_lds_kernel(const void *__restric
 
     if constexpr (kStaged) {
         __syncthreads();  // the last pass's image has been read by everyone
+        if constexpr (T % 16 == 0) {
+            c32 *w = lds + padded(g * N + lt);
 #pragma unroll
-        for (int m = 0; m < kPoints; ++m) {
-            int k = lt + T * m;
-            if constexpr (SHIFTED) k = (k + N / 2) & (N - 1);
-            lds[padded(g * N + k)] = r[m];
+            for (int m = 0; m < kPoints; ++m) {
+                // dsp::shift: bin k goes to (k + N/2) mod N, and N/2 = 8 T: slot m lands where slot (m + 8) mod 16 would
+                const int ms = SHIFTED ? ((m + kPoints / 2) & (kPoints - 1)) : m;
+                w[ms * (T + T / 16)] = r[m];
+            }
+        } else {
+#pragma unroll
+            for (int m = 0; m < kPoints; ++m) {
+                int k = lt + T * m;
+                if constexpr (SHIFTED) k = (k + N / 2) & (N - 1);
+                lds[padded(g * N + k)] = r[m];
+            }
         }
         __syncthreads();
         c32 *dst = out + tile * kTile;
         if (tile_points == static_cast<size_t>(kTile)) {
+            const c32 *rd = lds + padded(2 * tid);
 #pragma unroll
             for (int m = 0; m < kPoints / 2; ++m) {
-                const int e = 2 * (tid + kThreads * m);
-                const c32 p0 = lds[padded(e)], p1 = lds[padded(e) + 1];
-                store_stream_f4(reinterpret_cast<float *>(dst + e), p0.x, p0.y, p1.x, p1.y);
+                const c32 p0 = rd[m * (2 * kThreads + 2 * kThreads / 16)], p1 = rd[m * (2 * kThreads + 2 * kThreads / 16) + 1];
+                store_stream_f4(reinterpret_cast<float *>(dst + 2 * (tid + kThreads * m)), p0.x, p0.y, p1.x, p1.y);
             }
         } else {
 #pragma unroll

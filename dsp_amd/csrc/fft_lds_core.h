@@ -32,6 +32,10 @@ DSP_DEV void lds_exchange(c32 (&r)[kPoints], c32 *lds, int lt, int base) {
             c32 *w = lds + padded(base + stockham_dest<R, NS>(j, 0));
 #pragma unroll
             for (int u = 0; u < R; ++u) w[u * (NS + NS / 16)] = r[s + u * B];
+        } else if constexpr (NS == 1 && R == 16) {  // first exchange: 16 j + u, and base is a multiple of 16: one padding group
+            c32 *w = lds + padded(base + 16 * j);
+#pragma unroll
+            for (int u = 0; u < R; ++u) w[u] = r[s + u * B];
         } else {
 #pragma unroll
             for (int u = 0; u < R; ++u) lds[padded(base + stockham_dest<R, NS>(j, u))] = r[s + u * B];
