@@ -50,9 +50,9 @@ namespace {
 using namespace iirb;  // the recursion step, the row runners and the batch kernel: iir_batch_core.h
 
 // the float rows of the scan below, in the fast (double, fused multiply-add) arithmetic
-template <int P, int LEN, bool STORE, typename C>
+template <int P, int LEN, bool STORE, bool UNIT = false, typename C>
 DSP_DEV void run_row4(float *row, double (&xh)[P], double (&vh)[P], const C &co) {
-    run_rowv<P, LEN, STORE, IIR_ARITH_FMA>(row, xh, vh, co);
+    run_rowv<P, LEN, STORE, IIR_ARITH_FMA, UNIT>(row, xh, vh, co);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -211,7 +211,9 @@ DSP_DEV void wave_scan(SVec<P, WIDE> &S, const double *__restrict__ mats, int le
 }
 
 // mats: slots [0..8] = A^(32*2^j) (j = 8 is the whole-tile matrix), companion A in the vh ordering.
-template <int P, int MODE, bool ALIGNED, bool WIDE>
+// UNIT: the host has checked c0 == 1, d0 == 0 (iir_step_out) -- a separate instantiation, not a branch inside the
+// kernel: with both row runners in one kernel the unrolled code outgrew what the scan tolerates and it ran 7 % slower.
+template <int P, int MODE, bool ALIGNED, bool WIDE, bool UNIT = false>
 __global__ __launch_bounds__(kSt) void iir_scan_kernel(const float *__restrict__ x, float *__restrict__ y, size_t n,
                                                        IirCoef co, const double *__restrict__ mats,
                                                        const double *__restrict__ state_in,
@@ -304,7 +306,7 @@ __global__ __launch_bounds__(kSt) void iir_scan_kernel(const float *__restrict__
     }
     if (SCAN_ABLATED(1)) {
     } else if (MODE == SCAN_REDUCE || last_row) run_row4<P, kRow, false>(row, xh, vh, co);
-    else run_row4<P, kRow, true>(row, xh, vh, co);
+    else run_row4<P, kRow, true, UNIT>(row, xh, vh, co);
     SVec<P, WIDE> S;
     sv_zero<P, WIDE>(S);
 #pragma unroll
@@ -361,7 +363,7 @@ __global__ __launch_bounds__(kSt) void iir_scan_kernel(const float *__restrict__
         }
     }
     if (last_row) {  // the exact recursion from the true start state; also yields the state handed back
-        run_row_partial<P, true>(row, static_cast<int>(n - g0), xh, vh, co);
+        run_row_partial<P, true, IIR_ARITH_FMA, UNIT>(row, static_cast<int>(n - g0), xh, vh, co);
         if (state_out) {
             double *so = state_out + ch * 2 * P;
 #pragma unroll
@@ -379,10 +381,17 @@ __global__ __launch_bounds__(kSt) void iir_scan_kernel(const float *__restrict__
             float *e = reinterpret_cast<float *>(&q);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                double corr = 0.0;
+                if constexpr (UNIT) {  // c0 == 1: the correction accumulates onto the sample itself
+                    double acc = static_cast<double>(e[k]);
 #pragma unroll
-                for (int i = 0; i < P; ++i) corr = fma(hrow[(t4 + k) * P + i], vh[i], corr);
-                e[k] = static_cast<float>(fma(corr, co.c0, static_cast<double>(e[k])));
+                    for (int i = 0; i < P; ++i) acc = fma(hrow[(t4 + k) * P + i], vh[i], acc);
+                    e[k] = static_cast<float>(acc);
+                } else {
+                    double corr = 0.0;
+#pragma unroll
+                    for (int i = 0; i < P; ++i) corr = fma(hrow[(t4 + k) * P + i], vh[i], corr);
+                    e[k] = static_cast<float>(fma(corr, co.c0, static_cast<double>(e[k])));
+                }
             }
             *reinterpret_cast<float4 *>(row + t4) = q;
         }
@@ -716,6 +725,13 @@ int scan_launch(const float *x, float *y, size_t channels, size_t n, const IirCo
     // (capping the one-wave workgroups per CU with unused LDS, which helps iir_batch_kernel, costs the scan: 14 per CU
     // 0.446 ms, 8 per CU 0.502, 4 per CU 0.641 on a box where the plain launch took 0.436-0.446)
     if (fused) {
+        if constexpr (P <= 4 && ALIGNED && !WIDE) {  // the default output stage (iir_step_out), the common orders only
+            if (co.c0 == 1.0 && co.d0 == 0.0) {
+                hipLaunchKernelGGL((iir_scan_kernel<P, SCAN_FUSED, ALIGNED, WIDE, true>), grid, dim3(kSt), 0, s, x, y, n, co, d_table,
+                                   state_in, state, nullptr, nullptr, ntiles, warm, levels, d_table + 18 * ms, 0);
+                return check_launch("iir_scan_kernel<fused, unit output stage>");
+            }
+        }
         hipLaunchKernelGGL((iir_scan_kernel<P, SCAN_FUSED, ALIGNED, WIDE>), grid, dim3(kSt), 0, s, x, y, n, co, d_table,
                            state_in, state, nullptr, nullptr, ntiles, warm, levels, d_table + 18 * ms, 0);
         return check_launch("iir_scan_kernel<fused>");
