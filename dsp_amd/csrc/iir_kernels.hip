@@ -212,7 +212,8 @@ DSP_DEV void wave_scan(SVec<P, WIDE> &S, const double *__restrict__ mats, int le
 
 // mats: slots [0..8] = A^(32*2^j) (j = 8 is the whole-tile matrix), companion A in the vh ordering.
 // UNIT: the host has checked c0 == 1, d0 == 0 (iir_step_out) -- a separate instantiation, not a branch inside the
-// kernel: with both row runners in one kernel the unrolled code outgrew what the scan tolerates and it ran 7 % slower.
+// kernel: with both row runners and both correction loops in one kernel it ran 7 % slower instead of 6 % faster
+// (profiles/r03_iir_scan_unit_stage_ab.txt; not an instruction-cache effect, scripts/pmc_icache.sh).
 template <int P, int MODE, bool ALIGNED, bool WIDE, bool UNIT = false>
 __global__ __launch_bounds__(kSt) void iir_scan_kernel(const float *__restrict__ x, float *__restrict__ y, size_t n,
                                                        IirCoef co, const double *__restrict__ mats,
