@@ -160,3 +160,24 @@ def test_double_sample_filters_random_shapes(ops, dev, orc, seed):
         # the reference's own arithmetic: bit for bit (two poles = Coefficients<2>, the BiQuad specialisation: coefficients.h:172-182)
         want_ref = orc.biquad(x, a, b) if poles == 2 else want
         assert np.array_equal(ops.iir_f64(xd, a, b, mode="batch_ref").cpu().numpy(), want_ref), ("iir ref", poles, channels, n)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(SEEDS))
+def test_moving_average_long_channels_random_windows(ops, dev, orc, seed):
+    """Channels long enough for interior tiles (the path with the chunk-prefix differences formed per chunk and carry bit) with
+    windows of every size and parity up to the limit, lengths of every alignment, both sample types."""
+    import torch
+    rng = np.random.default_rng(5000 + seed)
+    for _ in range(4):
+        channels, n = int(rng.integers(1, 4)), int(rng.integers(5000, 60000))
+        pts = int(rng.integers(1, min(8192, n) + 1))
+        if rng.integers(0, 2):
+            pts = int(rng.integers(1, 700))
+        x = rng.standard_normal((channels, n)) + float(rng.integers(0, 2))  # sometimes a DC offset: long prefix sums
+        want = orc.moving_average(x, pts)
+        got = ops.moving_average_f64(torch.from_numpy(x).to(dev), pts).cpu().numpy()
+        assert rel_l2(got, want) <= 1e-11, ("double", channels, n, pts)
+        x32 = x.astype(np.float32)
+        got = ops.moving_average(torch.from_numpy(x32).to(dev), pts).cpu().numpy()
+        assert rel_l2(got, orc.moving_average(x32.astype(np.float64), pts)) <= 2e-6, ("float", channels, n, pts)
