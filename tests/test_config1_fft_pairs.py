@@ -4,8 +4,10 @@ resources/sine.wav, one channel.  The reference's eval/fft_pairs program is a GU
 (fft.h:57-83), FORWARD then INVERSE, divide by 1024 (nothing normalises, fft.h:40-54), compare with the
 input.  CPU: the reference path (oracle).  GPU: the same frames through the C ABI.
 
-The reference's own resources/sine.wav (2 ch, 16-bit PCM, 44.1 kHz) is used where /root/reference exists;
-elsewhere a WAV of the same format is synthesised (the reference cannot travel to the GPU box).
+The reference's own resources/sine.wav (2 ch, 16-bit PCM, 44.1 kHz) is used where /root/reference exists.  Elsewhere (the
+GPU box: the reference cannot travel) the frames come from tests/golden/sine_wav_ch0_head.npz, the first 128 frames of that
+file's channel 0 as the integers it holds (data, made by tests/golden/make_sine_fixture.py), written out and read back
+through the same WAV reader.
 """
 import os
 
@@ -25,11 +27,12 @@ def frames(tmp_path_factory):
         x, rate = wav.read(REF_WAV)
         assert x.shape[1] == 2 and rate == 44100
     else:
-        t = np.arange(44100 * 4) / 44100.0
-        s = 0.5 * np.sin(2 * np.pi * 440.0 * t)
+        fix = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sine_wav_ch0_head.npz"))
+        s = fix["pcm16"].astype(np.float64) / 32768.0
         p = tmp_path_factory.mktemp("wav") / "sine.wav"
-        wav.write_pcm16(str(p), np.stack([s, s], axis=1), 44100)
+        wav.write_pcm16(str(p), np.stack([s, s], axis=1), int(fix["rate"]))
         x, rate = wav.read(str(p))
+        assert np.array_equal(np.round(x[:, 0].astype(np.float64) * 32768.0).astype(np.int16), fix["pcm16"])
     ch0 = x[:, 0]
     n = (ch0.size // FRAME) * FRAME
     return ch0[:n].reshape(-1, FRAME)
