@@ -80,7 +80,7 @@ __device__ __forceinline__ size_t xcd_tile_of(unsigned block, size_t chunk) {
 // never share scratch memory (capi.hip).  Slots keep independent users (host staging in/out, FFT scratch, ...) of one
 // call from aliasing.  `s` is the stream the caller launches on.
 enum WorkspaceSlot {
-    WS_STAGE_IN = 0, WS_STAGE_OUT, WS_SCRATCH_A, WS_SCRATCH_B, WS_STATE, WS_STATE_SNAP, WS_IIR_TABLE, WS_FIR_HIST, WS_SLOTS
+    WS_STAGE_IN = 0, WS_STAGE_OUT, WS_SCRATCH_A, WS_SCRATCH_B, WS_STATE, WS_STATE_SNAP, WS_IIR_TABLE, WS_FIR_HIST, WS_COUNTERS, WS_SLOTS
 };
 int workspace(WorkspaceSlot slot, size_t bytes, void **ptr, hipStream_t s);
 // Lets kernel `fn` use up to the CU's whole 160 KiB of dynamic LDS; issued once per kernel and device, not per launch.

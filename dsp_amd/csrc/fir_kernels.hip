@@ -710,7 +710,7 @@ constexpr size_t kOsWave2LdsBytes = kOsWaveHalfPad * sizeof(c32) + kOsWave2Waves
 template <int I0>
 __global__ __launch_bounds__(kOsWave2Threads) void fir_os_wave2_kernel(
     const float *__restrict__ x, float *__restrict__ y, size_t n, const c32 *__restrict__ hspec, unsigned blocks_per_channel,
-    size_t total_blocks, size_t tiles, unsigned run_len, size_t runs_per_xcd) {
+    size_t total_blocks, size_t tiles, unsigned run_len, size_t runs_per_xcd, unsigned *__restrict__ draw, unsigned chunk) {
     constexpr int T = 64, P = kWavePoints;
     constexpr long long L = kWaveN - 256 * I0;
     typedef float f4 __attribute__((ext_vector_type(4)));
@@ -728,24 +728,53 @@ __global__ __launch_bounds__(kOsWave2Threads) void fir_os_wave2_kernel(
     const c32 *hlo = hs + lane;                  // H[lane + 64 m],         m < 32
     const c32 *hhi = hs + (kWaveN / 2 - lane);   // H[4096 - (lane + 64 m)], m >= 32:  hhi[-64 (m - 32)]
     const long long nn = static_cast<long long>(n);
-    // each XCD works through one contiguous range of runs (workgroups b and b + 8 share an XCD)
-    const size_t run = (blockIdx.x & 7u) * runs_per_xcd + static_cast<size_t>(blockIdx.x >> 3) * kOsWave2Waves + wave;
-    const size_t tile0 = run * run_len;
-    if ((static_cast<size_t>(blockIdx.x >> 3) * kOsWave2Waves + wave) >= runs_per_xcd || tile0 >= tiles) return;
-    // (channel, block) of the first block of the pair, stepped by two blocks per pair
-    size_t ch = (2 * tile0) / blocks_per_channel;
-    unsigned blk = static_cast<unsigned>((2 * tile0) % blocks_per_channel);
+    // Which pairs a wave takes.  draw != nullptr (the default, late round 3): the eight XCDs own the eighths [x chunk,
+    // (x + 1) chunk) of the pair list and every wave DRAWS its next `run_len` consecutive pairs from its XCD's counter when
+    // it is free -- the pairs are then worked in the order in which waves become free, as a grid of one-pair workgroups would
+    // be dispatched, and the waves of a SIMD stay out of step.  With the pairs dealt out in advance (draw == nullptr: each
+    // XCD a contiguous range of runs, workgroups b and b + 8 sharing an XCD) the same kernel is 9-12 % slower and its
+    // memory side alone 6-14 % (scripts/os_skeleton.hip, scripts/os_quad_ablate.hip, profiles/r03_fir_os_drawn_pairs.txt).
+    // Every wave leaves the loop: the counter only grows.
+    const unsigned xcd = blockIdx.x & 7u;
     // rows 64 - 4 I0 .. 63 of the last pair's second block = rows 0 .. 4 I0 - 1 of the next pair's first: kept in registers
     // while they fit (hops from 2560 samples up; below that 28 or 32 more registers would spill, and the rows are read again)
     constexpr bool KEEP = I0 <= 6;
     constexpr int kKeep = KEEP ? 4 * I0 : 1;
     float keep[kKeep];
-    bool have_keep = false;
 #pragma unroll
     for (int m = 0; m < kKeep; ++m) keep[m] = 0.0f;
-    for (unsigned pp = 0; pp < run_len; ++pp) {
-        const size_t tile = tile0 + pp;
-        if (tile >= tiles) break;
+    for (bool first = true;; first = false) {
+    size_t tile0, tile_end;
+    if (draw) {
+        unsigned t = 0;
+        if (lane == 0) t = atomicAdd(draw + 32 * xcd, run_len);
+        t = __builtin_amdgcn_readfirstlane(t);
+        if (t >= chunk) break;
+        tile0 = static_cast<size_t>(xcd) * chunk + t;
+        tile_end = static_cast<size_t>(xcd) * chunk + (t + run_len < chunk ? t + run_len : chunk);
+    } else {
+        if (!first) break;
+        const size_t run = xcd * runs_per_xcd + static_cast<size_t>(blockIdx.x >> 3) * kOsWave2Waves + wave;
+        tile0 = run * run_len;
+        tile_end = tile0 + run_len;
+        if ((static_cast<size_t>(blockIdx.x >> 3) * kOsWave2Waves + wave) >= runs_per_xcd) break;
+    }
+    if (tile_end > tiles) tile_end = tiles;
+    if (tile0 >= tile_end) continue;
+    // (channel, block) of the first block of the pair, stepped by two blocks per pair (drawn pairs: the host has checked
+    // that block numbers fit 32 bits)
+    size_t ch;
+    unsigned blk;
+    if (draw) {
+        const unsigned q = 2u * static_cast<unsigned>(tile0);
+        ch = q / blocks_per_channel;
+        blk = q % blocks_per_channel;
+    } else {
+        ch = (2 * tile0) / blocks_per_channel;
+        blk = static_cast<unsigned>((2 * tile0) % blocks_per_channel);
+    }
+    bool have_keep = false;
+    for (size_t tile = tile0; tile < tile_end; ++tile) {
         const size_t ch_a = ch;
         const unsigned blk_a = blk;
         const bool wrap = blk_a + 1 == blocks_per_channel;
@@ -806,6 +835,7 @@ __global__ __launch_bounds__(kOsWave2Threads) void fir_os_wave2_kernel(
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
     }
+    }  // draws / the one dealt run
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1317,13 +1347,30 @@ int launch_os(const float *x, float *y, size_t channels, size_t n, const c32 *d_
             if (const char *e = getenv("DSP_GPU_OS_WAVE_RUN"))  // tests: runs of several pairs on inputs too small to get them
                 if (atoi(e) > 0) run_len = static_cast<unsigned>(atoi(e));
             const size_t runs = (tiles + run_len - 1) / run_len;
-            const size_t runs_per_xcd = ((runs + 7) / 8 + kOsWave2Waves - 1) / kOsWave2Waves * kOsWave2Waves;
-            const dim3 grid2(static_cast<unsigned>(runs_per_xcd / kOsWave2Waves * 8));
+            size_t runs_per_xcd = ((runs + 7) / 8 + kOsWave2Waves - 1) / kOsWave2Waves * kOsWave2Waves;
+            dim3 grid2(static_cast<unsigned>(runs_per_xcd / kOsWave2Waves * 8));
+            // Default: the pairs are DRAWN, one workgroup per CU, from eight counters (one per XCD, 128 bytes apart) that a
+            // memset on the caller's stream clears in front of the launch.  DSP_GPU_OS_WAVE_DRAW=0: dealt out in runs as until
+            // late round 3; =<k>: k consecutive pairs per draw (inside a draw the shared rows stay in registers).
+            unsigned *d_draw = nullptr;
+            unsigned chunk2 = 0;
+            int draw_len = getenv("DSP_GPU_OS_WAVE_RUN") ? 0 : 1;  // (a test that sets the run length means the dealt form)
+            if (const char *e = getenv("DSP_GPU_OS_WAVE_DRAW")) draw_len = atoi(e);
+            if (draw_len > 0 && total_blocks < 0xffffffffull) {
+                void *p = nullptr;
+                if (int rc = workspace(WS_COUNTERS, 8 * 32 * sizeof(unsigned), &p, s)) return rc;
+                d_draw = static_cast<unsigned *>(p);
+                DSPGPU_HIP(hipMemsetAsync(d_draw, 0, 8 * 32 * sizeof(unsigned), s));
+                chunk2 = static_cast<unsigned>((tiles + 7) / 8);
+                run_len = static_cast<unsigned>(draw_len);
+                runs_per_xcd = 0;
+                grid2 = dim3(static_cast<unsigned>((cus + 7) / 8 * 8));
+            }
 #define DSPGPU_OSW2_CASE(I0)                                                                                            \
     case I0: {                                                                                                          \
         if (int rc = allow_full_lds(reinterpret_cast<const void *>(fir_os_wave2_kernel<I0>))) return rc;                \
         hipLaunchKernelGGL(fir_os_wave2_kernel<I0>, grid2, dim3(kOsWave2Threads), kOsWave2LdsBytes, s, x, y, n, d_hspec, bpc, \
-                           total_blocks, tiles, run_len, runs_per_xcd);                                                 \
+                           total_blocks, tiles, run_len, runs_per_xcd, d_draw, chunk2);                                 \
     } break
             switch (static_cast<int>((kOsN - L) / 256)) {
                 DSPGPU_OSW2_CASE(1); DSPGPU_OSW2_CASE(2); DSPGPU_OSW2_CASE(3); DSPGPU_OSW2_CASE(4);

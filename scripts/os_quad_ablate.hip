@@ -40,7 +40,7 @@ __global__ __launch_bounds__(64) void check_kernel(const c32 *in, c32 *wide, c32
 template <int MODE, int WAVES, int I0>
 __global__ __launch_bounds__(WAVES * 64) void osq_kernel(const float *__restrict__ x, float *__restrict__ y, size_t n,
                                                          const c32 *__restrict__ hspec, unsigned bpc, size_t tiles,
-                                                         size_t chunk, float *sink) {
+                                                         size_t chunk, float *sink, unsigned *ctr = nullptr) {
     constexpr int T = 64, P = 64;
     constexpr long long L = kWaveN - 256 * I0;
     typedef float f4 __attribute__((ext_vector_type(4)));
@@ -54,7 +54,15 @@ __global__ __launch_bounds__(WAVES * 64) void osq_kernel(const float *__restrict
     const size_t xcd = blockIdx.x & 7u, wpx = static_cast<size_t>(gridDim.x >> 3) * WAVES;
     const c32 *hlo = hs + lane, *hhi = hs + (kWaveN / 2 - lane);
     float acc = 0.0f;
-    for (size_t t = static_cast<size_t>(blockIdx.x >> 3) * WAVES + wave; t < chunk; t += wpx) {
+    // ctr != nullptr: every wave DRAWS its next pair from its XCD's counter instead of striding (the order of the pairs then
+    // follows the order in which waves become free, as a grid of one-pair workgroups would)
+    for (size_t t = static_cast<size_t>(blockIdx.x >> 3) * WAVES + wave;; t += wpx) {
+        if (ctr) {
+            unsigned d = 0;
+            if (lane == 0) d = atomicAdd(ctr + 32 * xcd, 1u);
+            t = __builtin_amdgcn_readfirstlane(d);
+        }
+        if (t >= chunk) break;
         const size_t tile = xcd * chunk + t;
         if (tile >= tiles) break;
         const size_t qa = 2 * tile, qb = qa + 1;
@@ -340,7 +348,10 @@ int run_late(const char *name, const float *x, float *y, size_t n, size_t channe
 #define CK(e) do { hipError_t e_ = (e); if (e_ != hipSuccess) { printf("%s: %s\n", #e, hipGetErrorString(e_)); return 1; } } while (0)
 
 template <int MODE, int WAVES>
-int run(const char *name, const float *x, float *y, size_t n, size_t channels, const c32 *h, float *sink) {
+int run(const char *name, const float *x, float *y, size_t n, size_t channels, const c32 *h, float *sink, bool dyn = false) {
+    static unsigned *ctr_buf = nullptr;
+    if (!ctr_buf) CK(hipMalloc(&ctr_buf, 8 * 32 * sizeof(unsigned)));
+    unsigned *ctr = dyn ? ctr_buf : nullptr;
     constexpr int I0 = 2;
     const long long L = kWaveN - 256 * I0;
     const int ntaps = 511;
@@ -352,13 +363,15 @@ int run(const char *name, const float *x, float *y, size_t n, size_t channels, c
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
     const int wgs = 256;
-    for (int it = 0; it < 2; ++it)
-        hipLaunchKernelGGL((osq_kernel<MODE, WAVES, I0>), dim3(wgs), dim3(WAVES * 64), lds, 0, x, y, n, h, bpc, tiles, chunk, sink);
+    auto launch = [&] {
+        if (ctr) (void)hipMemsetAsync(ctr, 0, 8 * 32 * sizeof(unsigned), 0);
+        hipLaunchKernelGGL((osq_kernel<MODE, WAVES, I0>), dim3(wgs), dim3(WAVES * 64), lds, 0, x, y, n, h, bpc, tiles, chunk, sink, ctr);
+    };
+    for (int it = 0; it < 2; ++it) launch();
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0, 0));
     const int iters = 10;
-    for (int it = 0; it < iters; ++it)
-        hipLaunchKernelGGL((osq_kernel<MODE, WAVES, I0>), dim3(wgs), dim3(WAVES * 64), lds, 0, x, y, n, h, bpc, tiles, chunk, sink);
+    for (int it = 0; it < iters; ++it) launch();
     CK(hipEventRecord(e1, 0));
     CK(hipEventSynchronize(e1));
     float ms = 0;
@@ -408,12 +421,20 @@ int main() {
     rc |= run<3, 4>("loads + stores only, 4 waves/CU", x, y, n, channels, h, sink);
     rc |= run<15, 8>("full, 8 waves/CU", x, y, n, channels, h, sink);
     rc |= run<15, 4>("full, 4 waves/CU", x, y, n, channels, h, sink);
+    rc |= run<3, 8>("loads + stores only, 8 waves/CU, pairs drawn", x, y, n, channels, h, sink, true);
+    rc |= run<15, 8>("full, 8 waves/CU, pairs drawn", x, y, n, channels, h, sink, true);
+    rc |= run<15, 8>("full, 8 waves/CU (again)", x, y, n, channels, h, sink);
+    rc |= run<15, 8>("full, 8 waves/CU, pairs drawn (again)", x, y, n, channels, h, sink, true);
     rc |= run_seq<3, 8>("seq walk, loads + stores only, 8 waves", x, y, n, channels, h, sink, 2);
     rc |= run_seq<3, 8>("seq walk, loads + stores only, 8 waves", x, y, n, channels, h, sink, 8);
     rc |= run_seq<3, 4>("seq walk, loads + stores only, 4 waves", x, y, n, channels, h, sink, 1);
     rc |= run_seq<15, 8>("seq walk, full, 8 waves", x, y, n, channels, h, sink, 2);
     rc |= run_seq<15, 8>("seq walk, full, 8 waves", x, y, n, channels, h, sink, 4);
     rc |= run_seq<15, 8>("seq walk, full, 8 waves", x, y, n, channels, h, sink, 8);
+    for (unsigned rpc : {16u, 32u, 49u, 74u, 147u}) {  // short runs down to one pair per wave: many workgroups, dispatched as CUs free up
+        rc |= run_seq<3, 8>("seq walk, loads + stores only, 8 waves", x, y, n, channels, h, sink, rpc);
+        rc |= run_seq<15, 8>("seq walk, full, 8 waves", x, y, n, channels, h, sink, rpc);
+    }
     rc |= run_late<8, 7>("late prefetch, 8 waves/CU, 7 staged", x, y, n, channels, h, sink);
     rc |= run_late<8, 14>("late prefetch, 8 waves/CU, 14 staged", x, y, n, channels, h, sink);
     rc |= run_late<4, 7>("late prefetch, 4 waves/CU, 7 staged", x, y, n, channels, h, sink);

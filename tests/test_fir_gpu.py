@@ -399,6 +399,14 @@ def test_overlap_save_wave_kernel(ops, dev, orc, channels, n, ntaps, monkeypatch
         monkeypatch.setenv("DSP_GPU_OS_WAVE_RUN", str(run))
         assert np.array_equal(ops.convolve(xd, h, "overlap_save").cpu().numpy(), old_form), run
     monkeypatch.delenv("DSP_GPU_OS_WAVE_RUN")
+    # the default above DRAWS its pairs one at a time from a counter per XCD; the same with 2, 3 and 5 consecutive pairs per
+    # draw (kept rows in use inside a draw), twice in a row (the counters are cleared in front of every launch), and with the
+    # pairs dealt out in advance instead (DSP_GPU_OS_WAVE_DRAW=0)
+    for draw in (2, 3, 5, 0, 1):
+        monkeypatch.setenv("DSP_GPU_OS_WAVE_DRAW", str(draw))
+        for _ in range(2):
+            assert np.array_equal(ops.convolve(xd, h, "overlap_save").cpu().numpy(), old_form), draw
+    monkeypatch.delenv("DSP_GPU_OS_WAVE_DRAW")
     monkeypatch.setenv("DSP_GPU_OS_WAVE_MIN_TILES", "999999999")
     other = ops.convolve(xd, h, "overlap_save").cpu().numpy()
     assert rel_l2(g[1:-1], other) <= 5e-6
