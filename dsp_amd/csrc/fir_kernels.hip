@@ -735,7 +735,7 @@ __global__ __launch_bounds__(kOsWave2Threads) void fir_os_wave2_kernel(
     // XCD a contiguous range of runs, workgroups b and b + 8 sharing an XCD) the same kernel is 9-12 % slower and its
     // memory side alone 6-14 % (scripts/os_skeleton.hip, scripts/os_quad_ablate.hip, profiles/r03_fir_os_drawn_pairs.txt).
     // Every wave leaves the loop: the counter only grows.
-    const unsigned xcd = blockIdx.x & 7u;
+    const unsigned xcd = blockIdx.x & 7u;  // (one counter for the whole chip instead of one per XCD: 1.91 ms against 1.62)
     // rows 64 - 4 I0 .. 63 of the last pair's second block = rows 0 .. 4 I0 - 1 of the next pair's first: kept in registers
     // while they fit (hops from 2560 samples up; below that 28 or 32 more registers would spill, and the rows are read again)
     constexpr bool KEEP = I0 <= 6;
