@@ -163,7 +163,7 @@ def make_fir(torch, dev, ops, rank, mode):
     else:
         meta = dict(metric="fir_overlap_save_throughput", unit="GSamples/s", dtype="f32", bound="hbm",
                     alg_per_unit=8.0, alg_unit="bytes/sample (4 B read + 4 B write)",
-                    kernel="fir_os_wave2_kernel<2> (+ fir_overlap_save_kernel<12> on the 2 x 1,024 edge block pairs, ~36 us)")
+                    kernel="fir_os_wave2_kernel<2> (+ fir_overlap_save_kernel<12> on the 2 x 1,024 edge block pairs, ~36 us, and a 1 KB memset of the draw counters)")
         units = channels * n
     meta["config"] = {"workload": f"C3: 511-tap windowed-sinc FIR ({mode}), 1,024 ch x 2^20 samples fp32 noise, per GPU",
                       "channels": channels, "n": n, "ntaps": ntaps, "sharding": "channels, no collective"}
