@@ -23,7 +23,7 @@
  *   - Threads and streams.  Intended multi-GPU use is one host thread (or process) per device with that device
  *     made current (hipSetDevice) before the call.  The library's tables (tap cache, IIR plans) are locked and
  *     handed out pinned, and its growing device workspaces (the ping-pong slab of FFTs above 2^15 points, IIR
- *     tile carries and state snapshots, FIR history scratch, host staging) are kept PER (device, stream): calls
+ *     tile carries and state snapshots, FIR history scratch, the overlap-save FIR's draw counters, host staging) are kept PER (device, stream): calls
  *     on different streams of one device -- from one host thread or several -- never share scratch memory and may
  *     overlap freely (tests/test_streams_gpu.py).  What remains single-file: (i) calls that share ONE stream must
  *     come from one host thread at a time (the usual rule for a stream); (ii) DSP_GPU_MEM_HOST calls on one device
