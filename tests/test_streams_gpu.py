@@ -166,3 +166,28 @@ def test_host_calls_from_two_threads():
     assert not errors, errors
     for i in range(2):
         assert np.array_equal(got[i], want[i])
+
+
+def test_overlap_save_draw_counters_are_per_stream(monkeypatch):
+    """The one-shot overlap-save FIR's waves draw their block pairs from counters that a memset clears in front of every
+    launch; those counters belong to the (device, stream) workspace set.  Two streams run the wave kernel (forced onto
+    inputs this small) back to back, 40 calls each, on different inputs, every output compared bit for bit with the same call
+    made alone.  (With shared counters one stream's memset could land in the middle of the other's launch; on this chip
+    the two persistent launches mostly take turns, so the test guards the results rather than proving the hazard.)"""
+    dev = _dev()
+    monkeypatch.setenv("DSP_GPU_OS_WAVE_MIN_TILES", "1")
+    g = torch.Generator(device=dev).manual_seed(77)
+    taps = design.sinc(0.1, 511)
+    xs = [torch.randn(48, 1 << 16, device=dev, generator=g) for _ in range(2)]
+    want = [ops.convolve(x, taps, "overlap_save") for x in xs]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    outs = [[torch.full_like(xs[i], 7.0) for _ in range(40)] for i in range(2)]
+    for k in range(40):
+        for i, s in enumerate(streams):
+            with torch.cuda.stream(s):
+                ops.convolve(xs[i], taps, "overlap_save", out=outs[i][k])
+    torch.cuda.synchronize()
+    for i in range(2):
+        for o in outs[i]:
+            assert torch.equal(o, want[i])
