@@ -794,13 +794,17 @@ __global__ __launch_bounds__(kOsWave2Threads) void fir_os_wave2_kernel(
 #pragma unroll
             for (int m = 0; m < kKeep; ++m) r[m].x = keep[m];
         } else {
+            // (these rows are the last rows of the pair before, which a neighbouring wave of the same XCD reads at about the
+            // same time, and the last 4 I0 rows of block b are the next pair's first: both through the cache, the rest streams)
 #pragma unroll
-            for (int m = 0; m < 4 * I0; ++m) r[m].x = __builtin_nontemporal_load(pa + T * m);
+            for (int m = 0; m < 4 * I0; ++m) r[m].x = pa[T * m];
         }
 #pragma unroll
         for (int m = 4 * I0; m < P; ++m) r[m].x = __builtin_nontemporal_load(pa + T * m);
 #pragma unroll
-        for (int m = 4 * I0; m < P; ++m) r[m].y = __builtin_nontemporal_load(pb + T * m);
+        for (int m = 4 * I0; m < P - 4 * I0; ++m) r[m].y = __builtin_nontemporal_load(pb + T * m);
+#pragma unroll
+        for (int m = P - 4 * I0; m < P; ++m) r[m].y = pb[T * m];
 #pragma unroll
         for (int m = 0; m < 4 * I0; ++m) r[m].y = r[m + P - 4 * I0].x;  // hop = whole rows: block b starts inside block a
         if constexpr (KEEP) {
