@@ -425,6 +425,10 @@ int main() {
     rc |= run<15, 8>("full, 8 waves/CU, pairs drawn", x, y, n, channels, h, sink, true);
     rc |= run<15, 8>("full, 8 waves/CU (again)", x, y, n, channels, h, sink);
     rc |= run<15, 8>("full, 8 waves/CU, pairs drawn (again)", x, y, n, channels, h, sink, true);
+    rc |= run<15, 6>("full, 6 waves/CU, pairs drawn", x, y, n, channels, h, sink, true);
+    rc |= run<15, 4>("full, 4 waves/CU, pairs drawn", x, y, n, channels, h, sink, true);
+    rc |= run<3, 6>("loads + stores only, 6 waves/CU, pairs drawn", x, y, n, channels, h, sink, true);
+    rc |= run<15, 8>("full, 8 waves/CU, pairs drawn (third)", x, y, n, channels, h, sink, true);
     rc |= run_seq<3, 8>("seq walk, loads + stores only, 8 waves", x, y, n, channels, h, sink, 2);
     rc |= run_seq<3, 8>("seq walk, loads + stores only, 8 waves", x, y, n, channels, h, sink, 8);
     rc |= run_seq<3, 4>("seq walk, loads + stores only, 4 waves", x, y, n, channels, h, sink, 1);
