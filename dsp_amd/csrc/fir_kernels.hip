@@ -744,101 +744,101 @@ __global__ __launch_bounds__(kOsWave2Threads) void fir_os_wave2_kernel(
 #pragma unroll
     for (int m = 0; m < kKeep; ++m) keep[m] = 0.0f;
     for (bool first = true;; first = false) {
-    size_t tile0, tile_end;
-    if (draw) {
-        unsigned t = 0;
-        if (lane == 0) t = atomicAdd(draw + 32 * xcd, run_len);
-        t = __builtin_amdgcn_readfirstlane(t);
-        if (t >= chunk) break;
-        tile0 = static_cast<size_t>(xcd) * chunk + t;
-        tile_end = static_cast<size_t>(xcd) * chunk + (t + run_len < chunk ? t + run_len : chunk);
-    } else {
-        if (!first) break;
-        const size_t run = xcd * runs_per_xcd + static_cast<size_t>(blockIdx.x >> 3) * kOsWave2Waves + wave;
-        tile0 = run * run_len;
-        tile_end = tile0 + run_len;
-        if ((static_cast<size_t>(blockIdx.x >> 3) * kOsWave2Waves + wave) >= runs_per_xcd) break;
-    }
-    if (tile_end > tiles) tile_end = tiles;
-    if (tile0 >= tile_end) continue;
-    // (channel, block) of the first block of the pair, stepped by two blocks per pair (drawn pairs: the host has checked
-    // that block numbers fit 32 bits)
-    size_t ch;
-    unsigned blk;
-    if (draw) {
-        const unsigned q = 2u * static_cast<unsigned>(tile0);
-        ch = q / blocks_per_channel;
-        blk = q % blocks_per_channel;
-    } else {
-        ch = (2 * tile0) / blocks_per_channel;
-        blk = static_cast<unsigned>((2 * tile0) % blocks_per_channel);
-    }
-    bool have_keep = false;
-    for (size_t tile = tile0; tile < tile_end; ++tile) {
-        const size_t ch_a = ch;
-        const unsigned blk_a = blk;
-        const bool wrap = blk_a + 1 == blocks_per_channel;
-        const unsigned blk_b = wrap ? 0u : blk_a + 1;
-        blk += 2;
-        if (blk >= blocks_per_channel) blk -= blocks_per_channel, ++ch;
-        const long long in_a = static_cast<long long>(blk_a) * L, in_b = in_a + L;
-        // plain: both blocks exist, lie wholly inside ONE channel and neither is its block 0 (see fir_os_wave_kernel)
-        const bool plain = 2 * tile + 1 < total_blocks && blk_a != 0 && blk_b != 0 && in_b + kWaveN <= nn;
-        if (!plain) {
-            have_keep = false;
-            continue;
-        }
-        const float *pa = x + ch_a * n + static_cast<size_t>(in_a) + lane, *pb = pa + L;
-        c32 r[P];
-        if (KEEP && have_keep) {
-#pragma unroll
-            for (int m = 0; m < kKeep; ++m) r[m].x = keep[m];
+        size_t tile0, tile_end;
+        if (draw) {
+            unsigned t = 0;
+            if (lane == 0) t = atomicAdd(draw + 32 * xcd, run_len);
+            t = __builtin_amdgcn_readfirstlane(t);
+            if (t >= chunk) break;
+            tile0 = static_cast<size_t>(xcd) * chunk + t;
+            tile_end = static_cast<size_t>(xcd) * chunk + (t + run_len < chunk ? t + run_len : chunk);
         } else {
-            // (these rows are the last rows of the pair before, which a neighbouring wave of the same XCD reads at about the
-            // same time, and the last 4 I0 rows of block b are the next pair's first: both through the cache, the rest streams)
-#pragma unroll
-            for (int m = 0; m < 4 * I0; ++m) r[m].x = pa[T * m];
+            if (!first) break;
+            const size_t run = xcd * runs_per_xcd + static_cast<size_t>(blockIdx.x >> 3) * kOsWave2Waves + wave;
+            tile0 = run * run_len;
+            tile_end = tile0 + run_len;
+            if ((static_cast<size_t>(blockIdx.x >> 3) * kOsWave2Waves + wave) >= runs_per_xcd) break;
         }
-#pragma unroll
-        for (int m = 4 * I0; m < P; ++m) r[m].x = __builtin_nontemporal_load(pa + T * m);
-#pragma unroll
-        for (int m = 4 * I0; m < P - 4 * I0; ++m) r[m].y = __builtin_nontemporal_load(pb + T * m);
-#pragma unroll
-        for (int m = P - 4 * I0; m < P; ++m) r[m].y = pb[T * m];
-#pragma unroll
-        for (int m = 0; m < 4 * I0; ++m) r[m].y = r[m + P - 4 * I0].x;  // hop = whole rows: block b starts inside block a
-        if constexpr (KEEP) {
-#pragma unroll
-            for (int m = 0; m < 4 * I0; ++m) keep[m] = r[m + P - 4 * I0].y;
-            have_keep = true;
+        if (tile_end > tiles) tile_end = tiles;
+        if (tile0 >= tile_end) continue;
+        // (channel, block) of the first block of the pair, stepped by two blocks per pair (drawn pairs: the host has checked
+        // that block numbers fit 32 bits)
+        size_t ch;
+        unsigned blk;
+        if (draw) {
+            const unsigned q = 2u * static_cast<unsigned>(tile0);
+            ch = q / blocks_per_channel;
+            blk = q % blocks_per_channel;
+        } else {
+            ch = (2 * tile0) / blocks_per_channel;
+            blk = static_cast<unsigned>((2 * tile0) % blocks_per_channel);
         }
+        bool have_keep = false;
+        for (size_t tile = tile0; tile < tile_end; ++tile) {
+            const size_t ch_a = ch;
+            const unsigned blk_a = blk;
+            const bool wrap = blk_a + 1 == blocks_per_channel;
+            const unsigned blk_b = wrap ? 0u : blk_a + 1;
+            blk += 2;
+            if (blk >= blocks_per_channel) blk -= blocks_per_channel, ++ch;
+            const long long in_a = static_cast<long long>(blk_a) * L, in_b = in_a + L;
+            // plain: both blocks exist, lie wholly inside ONE channel and neither is its block 0 (see fir_os_wave_kernel)
+            const bool plain = 2 * tile + 1 < total_blocks && blk_a != 0 && blk_b != 0 && in_b + kWaveN <= nn;
+            if (!plain) {
+                have_keep = false;
+                continue;
+            }
+            const float *pa = x + ch_a * n + static_cast<size_t>(in_a) + lane, *pb = pa + L;
+            c32 r[P];
+            if (KEEP && have_keep) {
+#pragma unroll
+                for (int m = 0; m < kKeep; ++m) r[m].x = keep[m];
+            } else {
+                // (these rows are the last rows of the pair before, which a neighbouring wave of the same XCD reads at about the
+                // same time, and the last 4 I0 rows of block b are the next pair's first: both through the cache, the rest streams)
+#pragma unroll
+                for (int m = 0; m < 4 * I0; ++m) r[m].x = pa[T * m];
+            }
+#pragma unroll
+            for (int m = 4 * I0; m < P; ++m) r[m].x = __builtin_nontemporal_load(pa + T * m);
+#pragma unroll
+            for (int m = 4 * I0; m < P - 4 * I0; ++m) r[m].y = __builtin_nontemporal_load(pb + T * m);
+#pragma unroll
+            for (int m = P - 4 * I0; m < P; ++m) r[m].y = pb[T * m];
+#pragma unroll
+            for (int m = 0; m < 4 * I0; ++m) r[m].y = r[m + P - 4 * I0].x;  // hop = whole rows: block b starts inside block a
+            if constexpr (KEEP) {
+#pragma unroll
+                for (int m = 0; m < 4 * I0; ++m) keep[m] = r[m + P - 4 * I0].y;
+                have_keep = true;
+            }
 
-        fft4096_wave_quad<+1>(r, img, lane);
+            fft4096_wave_quad<+1>(r, img, lane);
 #pragma unroll
-        for (int m = 0; m < P; ++m) {  // bin k = lane + 64 m
-            if (m < P / 2) r[m] = cmul(r[m], hlo[T * m]);
-            else r[m] = cmul_conj(r[m], hhi[-T * (m - P / 2)]);
-        }
-        fft4096_wave_quad<-1>(r, img, lane);
+            for (int m = 0; m < P; ++m) {  // bin k = lane + 64 m
+                if (m < P / 2) r[m] = cmul(r[m], hlo[T * m]);
+                else r[m] = cmul_conj(r[m], hhi[-T * (m - P / 2)]);
+            }
+            fft4096_wave_quad<-1>(r, img, lane);
 
-        // outputs k in [256 * I0, 4096) of both blocks are kept; each plane is re-laid out through the image so that a lane
-        // owns 4 consecutive outputs and a wave instruction writes 1 KB
-        float *const ya = y + ch_a * n + static_cast<size_t>(in_a) + 4 * lane, *const yb = ya + L;
+            // outputs k in [256 * I0, 4096) of both blocks are kept; each plane is re-laid out through the image so that a lane
+            // owns 4 consecutive outputs and a wave instruction writes 1 KB
+            float *const ya = y + ch_a * n + static_cast<size_t>(in_a) + 4 * lane, *const yb = ya + L;
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
+            for (int half = 0; half < 2; ++half) {
 #pragma unroll
-            for (int m = 4 * I0; m < P; ++m) img[(m - 4 * I0) * 64 + lane] = half ? r[m].y : r[m].x;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            f4 v[16 - I0];
+                for (int m = 4 * I0; m < P; ++m) img[(m - 4 * I0) * 64 + lane] = half ? r[m].y : r[m].x;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                f4 v[16 - I0];
 #pragma unroll
-            for (int i = I0; i < 16; ++i) v[i - I0] = *reinterpret_cast<const f4 *>(img + 256 * (i - I0) + 4 * lane);
+                for (int i = I0; i < 16; ++i) v[i - I0] = *reinterpret_cast<const f4 *>(img + 256 * (i - I0) + 4 * lane);
 #pragma unroll
-            for (int i = I0; i < 16; ++i) __builtin_nontemporal_store(v[i - I0], reinterpret_cast<f4 *>((half ? yb : ya) + 256 * i));
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                for (int i = I0; i < 16; ++i) __builtin_nontemporal_store(v[i - I0], reinterpret_cast<f4 *>((half ? yb : ya) + 256 * i));
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
         }
-    }
     }  // draws / the one dealt run
 }
 
