@@ -468,3 +468,22 @@ def test_out_argument_is_validated(ops, dev):
             ops.iir(x, [0.5, 0.0], [0.0, 0.5], out=bad)
     with pytest.raises(capi.DspGpuError):
         ops.fft0(torch.zeros(4, 1024, dtype=torch.complex64, device=dev), out=torch.empty(4, 512, dtype=torch.complex64, device=dev))
+
+
+@pytest.mark.gpu
+def test_moving_average_tile_edge_shapes(ops, dev, orc):
+    """Channel lengths that are exact multiples of a tile (256 * 2^k outputs) or a few samples off, windows of 1 ... 257 points of
+    both parities (the window's length decides which chunk-prefix difference an output reads), both sample types."""
+    import torch
+    rng = np.random.default_rng(1)
+    for n in (256, 512, 1024, 2048, 4096, 8192, 12288, 4100, 8190, 16384 + 4):
+        for pts in (1, 2, 3, 4, 15, 16, 17, 31, 32, 33, 255, 256, 257):
+            if pts > n:
+                continue
+            x = rng.standard_normal((3, n)) + 1.0
+            want = orc.moving_average(x, pts)
+            got = ops.moving_average_f64(torch.from_numpy(x).to(dev), pts).cpu().numpy()
+            assert rel_l2(got, want) <= 1e-11, ("double", n, pts)
+            x32 = x.astype(np.float32)
+            got = ops.moving_average(torch.from_numpy(x32).to(dev), pts).cpu().numpy()
+            assert rel_l2(got, orc.moving_average(x32.astype(np.float64), pts)) <= 2e-6, ("float", n, pts)
