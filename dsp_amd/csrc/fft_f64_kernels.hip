@@ -6,6 +6,8 @@
 //   N <= 4096   fft64_tile_kernel: 256 threads x 16 register-resident points = one 4096-point tile (4096/N transforms),
 //               radix-16 Stockham passes, points exchanged through a padded LDS image of 68 KB (two workgroups per CU).
 //               32 B of HBM traffic per point: bound by HBM like its fp32 sibling (fp64 FMA rate is not the limit).
+//               Like the fp32 kernel: each XCD walks a contiguous eighth of the tiles, every global access is a use-once
+//               (non-temporal) 16-byte one, and rows shorter than 128 points move their tile coalesced through the image.
 //   N <= 2^18   N = N1*N2, both <= 512: two passes of the same kernel, the transposes folded into its loads and stores
 //               (a tile of 4096/N1 adjacent columns, then a tile of 4096/N2 adjacent rows written transposed): 64 B/point.
 //   N <= 2^24   N = N1*N2*N3, each 2^6 .. 2^8: three passes of that kernel (columns over n1, columns over n2 inside every
@@ -40,6 +42,14 @@ constexpr int kP64 = 16;                       // points per thread
 constexpr int kTile64 = kT64 * kP64;           // 4096 points per workgroup
 constexpr size_t kLds64Bytes = (kTile64 + kTile64 / 16) * sizeof(c64);  // 69,632
 D64_DEV int padded64(int i) { return i + (i >> 4); }
+D64_DEV c64 load_stream64(const c64 *p) {
+    const auto v = load_stream<double>(reinterpret_cast<const double *>(p));
+    return c64{v.x, v.y};
+}
+D64_DEV void store_stream64(c64 *p, c64 v) {
+    typename Smp<double>::vec w = {v.x, v.y};
+    store_stream<double>(reinterpret_cast<double *>(p), w);
+}
 
 constexpr double cos16d(int q) {
     constexpr double t[16] = {1.0, 0.92387953251128673848, 0.70710678118654752440, 0.38268343236508977173,
@@ -189,11 +199,17 @@ enum F64Mode { F64_ROWS = 0, F64_COLS = 1, F64_ROWS_T = 2 };
 
 template <int LOG2N, int SIGN, int MODE>
 __global__ __launch_bounds__(kT64) void fft64_tile_kernel(const c64 *in, c64 *out, size_t batch, int tw_log2, unsigned tw_rows,
-                                                          unsigned other, unsigned groups) {
+                                                          unsigned other, unsigned groups, size_t blocks, size_t chunk) {
     constexpr int N = 1 << LOG2N, T = N / kP64, PER_TILE = kTile64 / N;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     c64 *lds = reinterpret_cast<c64 *>(lds_raw);
     const int tid = threadIdx.x, xf = tid / T, lt = tid % T, base = xf * N;
+    const size_t block = xcd_tile_of(blockIdx.x, chunk);  // every XCD walks one contiguous eighth of the tiles
+    if (block >= blocks) return;
+    // Rows shorter than 128 points give a thread's neighbours runs of less than 128 bytes: their tile (one contiguous run of
+    // 4096 points) is moved with coalesced accesses and redistributed through the image instead.
+    constexpr bool STAGED = MODE == F64_ROWS && T < 8;
+    const size_t tile_e0 = block * kTile64, tile_end = batch * N;
     size_t q;          // F64_ROWS: transform index; otherwise the twiddle row (column index) / unused
     bool live = true;
     const c64 *mat_in = in;
@@ -201,12 +217,12 @@ __global__ __launch_bounds__(kT64) void fft64_tile_kernel(const c64 *in, c64 *ou
     unsigned first = 0;  // first column (F64_COLS) / first row (F64_ROWS_T) of the tile inside its matrix
     unsigned grp = 0;    // F64_ROWS_T: the tile's g
     if constexpr (MODE == F64_ROWS) {
-        q = static_cast<size_t>(blockIdx.x) * PER_TILE + xf;
+        q = block * PER_TILE + xf;
         live = q < batch;
     } else {
         const unsigned tiles = other / PER_TILE * groups;  // the launcher guarantees other % PER_TILE == 0
-        const size_t m = blockIdx.x / tiles;
-        const unsigned t = blockIdx.x % tiles;
+        const size_t m = block / tiles;
+        const unsigned t = static_cast<unsigned>(block % tiles);
         first = (t / groups) * PER_TILE;
         grp = t % groups;
         mat_in = in + m * static_cast<size_t>(N) * other * groups;
@@ -218,8 +234,22 @@ __global__ __launch_bounds__(kT64) void fft64_tile_kernel(const c64 *in, c64 *ou
 #pragma unroll
         for (int i = 0; i < kP64; ++i) {  // element e of column first + c sits at [e][first + c]: threads run along c
             const int idx = tid + kT64 * i, c = idx % PER_TILE, e = idx / PER_TILE;
-            lds[padded64(c * N + e)] = mat_in[static_cast<size_t>(e) * other + first + c];
+            lds[padded64(c * N + e)] = load_stream64(mat_in + static_cast<size_t>(e) * other + first + c);
         }
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < kP64; ++m) r[m] = lds[padded64(base + lt + T * m)];
+        __syncthreads();
+    } else if constexpr (STAGED) {
+        c64 v[kP64];
+#pragma unroll
+        for (int i = 0; i < kP64; ++i) {  // no branch around the loads: a point behind the batch is aimed at in[0] and zeroed
+            const size_t e = tile_e0 + tid + kT64 * i;
+            v[i] = load_stream64(in + (e < tile_end ? e : 0));
+            if (e >= tile_end) v[i] = c64{0.0, 0.0};
+        }
+#pragma unroll
+        for (int i = 0; i < kP64; ++i) lds[padded64(tid + kT64 * i)] = v[i];
         __syncthreads();
 #pragma unroll
         for (int m = 0; m < kP64; ++m) r[m] = lds[padded64(base + lt + T * m)];
@@ -227,7 +257,7 @@ __global__ __launch_bounds__(kT64) void fft64_tile_kernel(const c64 *in, c64 *ou
     } else if (live) {
         const c64 *src = (MODE == F64_ROWS ? in + q * N : mat_in + (static_cast<size_t>(first + xf) * groups + grp) * N) + lt;
 #pragma unroll
-        for (int m = 0; m < kP64; ++m) r[m] = src[T * m];
+        for (int m = 0; m < kP64; ++m) r[m] = load_stream64(src + T * m);
     } else {
 #pragma unroll
         for (int m = 0; m < kP64; ++m) r[m] = c64{0.0, 0.0};
@@ -243,7 +273,7 @@ __global__ __launch_bounds__(kT64) void fft64_tile_kernel(const c64 *in, c64 *ou
             pass64<R2, R0 * R1, LOG2N, SIGN>(r, lt);
         }
     }
-    if (MODE == F64_ROWS && !live) return;
+    if (MODE == F64_ROWS && !STAGED && !live) return;
     if (tw_log2 > 0) {
         // W^{row k}, k = lt + T m:  W^{row lt} (W^{row T})^m -- two sincos and a product tree
         const unsigned long long mask = (1ull << tw_log2) - 1ull, row = q % tw_rows;
@@ -256,10 +286,20 @@ __global__ __launch_bounds__(kT64) void fft64_tile_kernel(const c64 *in, c64 *ou
 #pragma unroll
         for (int m = 1; m < kP64; ++m) r[m] = cmul64(r[m], cmul64(w0, pw[m]));
     }
-    if constexpr (MODE == F64_ROWS) {
+    if constexpr (STAGED) {
+        __syncthreads();  // the last exchange's image has been read by everyone
+#pragma unroll
+        for (int m = 0; m < kP64; ++m) lds[padded64(base + lt + T * m)] = r[m];
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < kP64; ++i) {
+            const size_t e = tile_e0 + tid + kT64 * i;
+            if (e < tile_end) store_stream64(out + e, lds[padded64(tid + kT64 * i)]);
+        }
+    } else if constexpr (MODE == F64_ROWS) {
         c64 *dst = out + q * N + lt;
 #pragma unroll
-        for (int m = 0; m < kP64; ++m) dst[T * m] = r[m];
+        for (int m = 0; m < kP64; ++m) store_stream64(dst + T * m, r[m]);
     } else {
         // through the image once more so that threads run along the tile's columns (F64_COLS) / rows (F64_ROWS_T), which
         // are adjacent in the output: element e of transform c goes to out[e][first + c], rows `other` long
@@ -271,7 +311,7 @@ __global__ __launch_bounds__(kT64) void fft64_tile_kernel(const c64 *in, c64 *ou
         for (int i = 0; i < kP64; ++i) {
             const int idx = tid + kT64 * i, c = idx % PER_TILE, e = idx / PER_TILE;
             const size_t row = MODE == F64_COLS ? static_cast<size_t>(e) : static_cast<size_t>(e) * groups + grp;
-            mat_out[row * other + first + c] = lds[padded64(c * N + e)];
+            store_stream64(mat_out + row * other + first + c, lds[padded64(c * N + e)]);
         }
     }
 }
@@ -325,13 +365,14 @@ int launch_tile(const c64 *in, c64 *out, size_t batch, int direction, int tw_log
         if (other % per_tile != 0) return fail(DSP_GPU_EINVAL, "fft64_tile_kernel: %u is not a multiple of the tile's %zu", other, per_tile);
         blocks = batch * (other / per_tile) * groups;
     }
-    if (blocks > 0x7fffffffull) return fail(DSP_GPU_EUNSUPPORTED, "fft_batch_f64: batch too large for one launch");
+    const size_t chunk = (blocks + 7) / 8;  // tiles per XCD
+    if (8 * chunk > 0x7fffffffull) return fail(DSP_GPU_EUNSUPPORTED, "fft_batch_f64: batch too large for one launch");
     auto kf = fft64_tile_kernel<LOG2N, +1, MODE>;
     auto ki = fft64_tile_kernel<LOG2N, -1, MODE>;
     auto kern = direction == DSP_GPU_FORWARD ? kf : ki;
     if (int rc = allow_full_lds(reinterpret_cast<const void *>(kern))) return rc;
-    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks)), dim3(kT64), kLds64Bytes, s, in, out, batch, tw_log2, tw_rows, other,
-                       groups);
+    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(8 * chunk)), dim3(kT64), kLds64Bytes, s, in, out, batch, tw_log2, tw_rows, other,
+                       groups, blocks, chunk);
     return check_launch("fft64_tile_kernel");
 }
 

@@ -11,7 +11,7 @@ from dsp_amd import ops  # noqa: E402
 
 dev = torch.device("cuda:0")
 total = 1 << 26
-for log2n in (4, 8, 10, 12, 13, 14, 16, 18, 20, 24):
+for log2n in [int(a) for a in sys.argv[1:]] or (4, 8, 10, 12, 13, 14, 16, 18, 20, 24):
     n = 1 << log2n
     x = torch.view_as_complex(torch.randn(total // n, n, 2, device=dev, dtype=torch.float64))
     y = torch.empty_like(x)

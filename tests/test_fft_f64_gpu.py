@@ -88,6 +88,30 @@ def test_properties_at_size(ops, dev, log2n, batch):
     assert float(lin.abs().max()) <= 1e-11 * float(X.abs().max())
 
 
+@pytest.mark.parametrize("log2n", [4, 5, 6, 7, 8, 10, 12])
+def test_many_tiles_and_a_ragged_last_one(ops, dev, log2n):
+    """Several tiles per XCD (the workgroup -> tile map gives each XCD a contiguous eighth) and a last tile that is
+    partly behind the batch, on the staged short-row route (rows of fewer than 128 points) and on the direct one; out of
+    place and in place; against torch's double transform (FORWARD = N * ifft)."""
+    import torch
+    n = 1 << log2n
+    per_tile = 4096 // n
+    g = torch.Generator(device=dev).manual_seed(7000 + log2n)
+    for batch in (8 * 3 * per_tile + 37 % per_tile + 1, 11 * per_tile - 1, per_tile + 1):
+        x = torch.view_as_complex(torch.randn(batch, n, 2, device=dev, generator=g, dtype=torch.float64))
+        guard = torch.full((batch + 2, n), 7.0 + 0j, device=dev, dtype=torch.complex128)
+        out = guard[1:-1]
+        for inverse in (False, True):
+            ops.fft0_f64(x, inverse=inverse, out=out)
+            want = torch.fft.fft(x, dim=-1) if inverse else torch.fft.ifft(x, dim=-1) * n
+            err = torch.linalg.vector_norm(out - want, dim=-1) / torch.linalg.vector_norm(want, dim=-1)
+            assert float(err.max()) <= tight(log2n) * 4, (log2n, batch, inverse, int(err.argmax()))
+            assert bool((guard[0] == 7.0).all()) and bool((guard[-1] == 7.0).all())  # nothing written around the batch
+        buf = x.clone()
+        ops.fft0_f64(buf, out=buf)
+        assert torch.equal(buf, ops.fft0_f64(x))
+
+
 def test_fp32_route_agrees_with_double_route(ops, dev):
     """The benchmarked fp32 transform against the double one on the same float-exact samples."""
     import torch
