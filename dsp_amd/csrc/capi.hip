@@ -670,8 +670,11 @@ int iir_impl(const char *who, const T *x, T *y, size_t channels, size_t n, const
     const bool auto_mode = mode == DSP_GPU_IIR_AUTO;
     if (auto_mode)  // one lane per channel needs tens of thousands of channels to fill the chip; measured crossover on
                     // 2^28 samples in total (scripts/iir_auto_threshold.py): 16,384 ch scan 0.53 / batch 1.08 ms,
-                    // 32,768 ch 0.67 / 0.58 ms.  AUTO never picks the reference arithmetic.
-        mode = (channels < 24576 && n >= 2048 && poles <= 8) ? DSP_GPU_IIR_SCAN : DSP_GPU_IIR_BATCH;
+                    // 32,768 ch 0.67 / 0.58 ms.  Rows of 16,384 samples and more go to the scan at any channel count: a
+                    // wave of the batch kernel then walks 64 rows that lie 64 KB or more apart, which the memory system
+                    // serves at 0.44-0.59 of 8 TB/s against the scan's 0.62-0.69 (65,536 x 16,384 / 53,687 x 20,000 /
+                    // 32,768 x 32,768, profiles/r03_iir_batch_row_lengths.txt).  AUTO never picks the reference arithmetic.
+        mode = (((channels < 24576 && n >= 2048) || n >= 16384) && poles <= 8) ? DSP_GPU_IIR_SCAN : DSP_GPU_IIR_BATCH;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t bytes = channels * n * sizeof(T);
     if (device_overlap(x, y, bytes, mem)) {

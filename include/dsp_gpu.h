@@ -65,7 +65,7 @@ extern "C" {
                                       kept for measurement (one-shot calls, <= 1024 taps); AUTO never picks it */
 
 /* IIR execution mode */
-#define DSP_GPU_IIR_AUTO  0 /* SCAN below 24,576 channels of >= 2,048 samples (and <= 8 poles), else BATCH */
+#define DSP_GPU_IIR_AUTO  0 /* SCAN below 24,576 channels of >= 2,048 samples and for any channels of >= 16,384 samples (<= 8 poles), else BATCH */
 #define DSP_GPU_IIR_BATCH 1 /* one thread per channel, channels in parallel          */
 #define DSP_GPU_IIR_SCAN  2 /* block-parallel linear-recurrence scan inside a channel */
 #define DSP_GPU_IIR_BATCH_REF 3 /* BATCH in the REFERENCE'S OWN ARITHMETIC, operation for operation and in its order, with no
