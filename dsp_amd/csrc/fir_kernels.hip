@@ -1311,6 +1311,16 @@ size_t os_wave_min_tiles() {
     return kOsWaveMinTiles;
 }
 
+// Blocks per channel from which it does.  The wave kernel takes the pairs that lie wholly inside one channel and hold neither
+// its first nor its last block; the others go to the workgroup kernel, two workgroups per channel.  On channels of a few blocks
+// most pairs are such edge pairs and that split costs more than it gains -- 65,536 x 4,096 (one block per channel): 1.82 ms split
+// against 0.47 ms on the workgroup kernel alone; 8,192 x 32,768 (10 blocks): 0.55 / 0.49; 4,096 x 65,536 (19 blocks): 0.47 /
+// 0.53 (scripts/fir_mid_channels.py, profiles/r03_fir_mid_channels.txt).  A DSP_GPU_OS_WAVE_MIN_TILES override lifts this too.
+size_t os_wave_min_blocks_per_channel() {
+    const char *e = getenv("DSP_GPU_OS_WAVE_MIN_TILES");
+    return (e && *e) ? 1 : 14;
+}
+
 int launch_os(const float *x, float *y, size_t channels, size_t n, const c32 *d_hspec, int ntaps, const float *hist,
               int zero_head, const OsExtra &ex, int log2n, hipStream_t s) {
     const long long order = ntaps - 1;
@@ -1330,7 +1340,7 @@ int launch_os(const float *x, float *y, size_t channels, size_t n, const c32 *d_
     const unsigned bpc = static_cast<unsigned>(nblocks);
     const size_t total_blocks = channels * static_cast<size_t>(nblocks);
     const size_t tiles = (total_blocks + 1) / 2;  // two real blocks per complex transform, across channels if need be
-    if (log2n == 12 && tiles >= os_wave_min_tiles() && !hist && !ex.accumulate && !ex.zero_hist && ex.stride == n && ex.yoff == 0 &&
+    if (log2n == 12 && tiles >= os_wave_min_tiles() && static_cast<size_t>(nblocks) >= os_wave_min_blocks_per_channel() && !hist && !ex.accumulate && !ex.zero_hist && ex.stride == n && ex.yoff == 0 &&
         (L & 255) == 0 && L >= 2048 && L <= 3840 && (n & 3) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0 &&
         (reinterpret_cast<uintptr_t>(x) & 3) == 0) {
         static const int cus = [] {
