@@ -1325,24 +1325,40 @@ int launch_os(const float *x, float *y, size_t channels, size_t n, const c32 *d_
               int zero_head, const OsExtra &ex, int log2n, hipStream_t s) {
     const long long order = ntaps - 1;
     const long long kOsN = 1ll << log2n;
-    // hop between blocks: N - order at most; one-shot calls round it down to a multiple of 64 samples when that costs
-    // at most 1/32 of it (block starts, and with them every wave's loads and stores, then sit on 256-byte boundaries)
-    long long L = kOsN - order;
-    if (!hist && !ex.zero_hist) {
-        if ((L & 255) * 32 <= L && (L & ~255ll) >= 256) L &= ~255ll;       // 1 KB: what the one-wave kernel's 16-byte stores want
-        else if ((L & 63) * 32 <= L && (L & ~63ll) >= 64) L &= ~63ll;
-    }
     const long long nv = static_cast<long long>(n) + ((hist || ex.zero_hist) ? order : 0);  // length of the (virtual) signal
     const long long valid = nv > order ? nv - order : 0;
-    // block 0 delivers N - order outputs, every later block L
-    long long nblocks = valid > kOsN - order ? 1 + (valid - (kOsN - order) + L - 1) / L : 1;  // block 0 also zero-fills y[0, order)
+    // block 0 delivers N - order outputs, every later block L (block 0 also zero-fills y[0, order))
+    auto blocks_at = [&](long long hop_v) { return valid > kOsN - order ? 1 + (valid - (kOsN - order) + hop_v - 1) / hop_v : 1ll; };
+    // hop between blocks: N - order at most
+    long long L = kOsN - order;
+    // The one-wave-per-pair kernel wants a hop of whole 1-KB rows (256 samples; its 16-byte stores, the rows it shares between
+    // pairs) and is worth up to 1/16 more blocks for it: 127 taps, 1,024 x 2^20: 1.80 ms on the workgroup kernel at hop 3968,
+    // 1.6 ms on the wave kernel at hop 3840 (scripts/fir_crossover.py).
+    bool wave = false;
+    if (log2n == 12 && !hist && !ex.accumulate && !ex.zero_hist && ex.stride == n && ex.yoff == 0 && (n & 3) == 0 &&
+        (reinterpret_cast<uintptr_t>(y) & 15) == 0 && (reinterpret_cast<uintptr_t>(x) & 3) == 0) {
+        const long long L256 = L & ~255ll;
+        if (L256 >= 2048 && L256 <= 3840 && (L - L256) * 16 <= L) {
+            const long long nb = blocks_at(L256);
+            const size_t tl = (channels * static_cast<size_t>(nb) + 1) / 2;
+            if (tl >= os_wave_min_tiles() && static_cast<size_t>(nb) >= os_wave_min_blocks_per_channel()) {
+                wave = true;
+                L = L256;
+            }
+        }
+    }
+    // otherwise one-shot calls round it down to a multiple of 64 samples (256 if that is as cheap) when that costs at most 1/32
+    // of it (block starts, and with them every wave's loads and stores, then sit on 256-byte boundaries)
+    if (!wave && !hist && !ex.zero_hist) {
+        if ((L & 255) * 32 <= L && (L & ~255ll) >= 256) L &= ~255ll;
+        else if ((L & 63) * 32 <= L && (L & ~63ll) >= 64) L &= ~63ll;
+    }
+    const long long nblocks = blocks_at(L);
     const int hop = static_cast<int>(L);
     const unsigned bpc = static_cast<unsigned>(nblocks);
     const size_t total_blocks = channels * static_cast<size_t>(nblocks);
     const size_t tiles = (total_blocks + 1) / 2;  // two real blocks per complex transform, across channels if need be
-    if (log2n == 12 && tiles >= os_wave_min_tiles() && static_cast<size_t>(nblocks) >= os_wave_min_blocks_per_channel() && !hist && !ex.accumulate && !ex.zero_hist && ex.stride == n && ex.yoff == 0 &&
-        (L & 255) == 0 && L >= 2048 && L <= 3840 && (n & 3) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0 &&
-        (reinterpret_cast<uintptr_t>(x) & 3) == 0) {
+    if (wave) {
         static const int cus = [] {
             int dev = 0, v = 256;
             if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev);

@@ -5,10 +5,10 @@ import numpy as np, torch
 from dsp_amd import ops, design
 x = torch.randn(1024, 1 << 20, device="cuda")
 y = torch.empty_like(x)
-for ntaps in (15, 31, 63, 95, 127, 191, 255, 511, 1023, 2047, 4095, 8191, 32767):
+for ntaps in (3, 7, 15, 31, 63, 95, 127, 191, 255, 511, 1023, 2047, 4095, 8191, 32767):
     h = design.sinc(0.1, ntaps)
     row = [f"taps {ntaps:5d}"]
-    for mode in ("direct", "direct_valu", "overlap_save"):
+    for mode in ("direct", "direct_valu", "overlap_save", "auto"):
         if mode == "direct_valu" and ntaps > 1024: continue
         if mode == "direct" and ntaps > 4096: continue
         for _ in range(2): ops.convolve(x, h, mode, out=y)
