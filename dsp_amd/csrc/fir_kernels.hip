@@ -892,10 +892,16 @@ DSP_DEV int ma_pad(int i) { return i + ((i >> 4) * Smp<T>::kVec); }
 // drift.  LDS: T xs[ma_pad(span)], double pc[chunks], double wave_tot[8 per pair of rounds], double d1[tile / 16 + 1].
 // T = float (BASELINE's type) or double (SampleBuffer<double>, what the reference's own callers filter:
 // eval/moving_average_filter_demo/main.cpp:14).
-template <bool ALIGNED, int kMaPer, typename T = float>
+//
+// PERIODIC (many short channels): the channels lie one behind the other in memory, so the batch is filtered as ONE signal of
+// channels * period samples in full 4096-output tiles -- a kept output's window never leaves its channel (the first and last
+// `mid` outputs of a channel are zero, filter.h:88-98) -- and only the edge test and the even-P constant go by the position
+// inside the channel (j mod period).  One workgroup per channel would stage and scan 256-sample tiles, mostly launch overhead.
+template <bool ALIGNED, int kMaPer, typename T = float, bool PERIODIC = false>
 __global__ __launch_bounds__(kThreads) void moving_average_kernel(const T *__restrict__ x, T *__restrict__ y,
                                                                   size_t n, int npoints, int span, int cpt, int skip_lo,
-                                                                  int skip_n, double inv, int ld_mode, int halo) {  // inv = 1.0 / npoints (host)
+                                                                  int skip_n, double inv, int ld_mode, int halo,  // inv = 1.0 / npoints (host)
+                                                                  unsigned period) {
     using V = typename Smp<T>::vec;
     constexpr int kVec = Smp<T>::kVec;
     constexpr int kMaTile = kThreads * kMaPer;
@@ -921,7 +927,7 @@ __global__ __launch_bounds__(kThreads) void moving_average_kernel(const T *__res
     const int shift = static_cast<int>(first - seg0);                     // 0..kVec-1
     const T *xc = x + ch * n;
     T *yc = y + ch * n;
-    const T corr = ((npoints & 1) == 0 && npoints < nn) ? xc[npoints] : T(0);
+    const T corr = (!PERIODIC && (npoints & 1) == 0 && npoints < nn) ? xc[npoints] : T(0);
 
     int u0 = tid * kVec;
     if (ALIGNED) {
@@ -1031,6 +1037,33 @@ __global__ __launch_bounds__(kThreads) void moving_average_kernel(const T *__res
         if constexpr (sizeof(T) == 8) return (sum - dcorr) / static_cast<double>(npoints);
         else return static_cast<T>(fma(sum, inv, ncorr_inv));  // (sum - corr) / P in one operation; corr = 0 for odd P
     };
+    if constexpr (PERIODIC) {  // (the window fits the channel: the host has checked 2 mid + 1 <= period)
+        const unsigned long long j0 = static_cast<unsigned long long>(out0) + tid;
+        const size_t c0 = j0 / period;
+        const unsigned r0 = static_cast<unsigned>(j0 - c0 * period);
+        const unsigned umid = static_cast<unsigned>(mid), uhi = period - umid;
+        const bool even = (npoints & 1) == 0;
+#pragma unroll
+        for (int i = 0; i < kMaPer; ++i) {
+            const int jrel = kThreads * i + tid;
+            const long long j = out0 + jrel;
+            if (j >= nn) continue;
+            unsigned r = r0 + kThreads * i;
+            const unsigned q = r / period;
+            r -= q * period;
+            T v = T(0);
+            if (r >= umid && r < uhi) {
+                const int lo = jrel + shift, up = lo + window;
+                const double sum = (pc[up >> 4] - pc[lo >> 4]) +
+                                   (static_cast<double>(xs[ma_pad<T>(up)]) - static_cast<double>(xs[ma_pad<T>(lo)]));
+                const double dc = even ? static_cast<double>(xc[(c0 + q) * period + npoints]) : 0.0;
+                if constexpr (sizeof(T) == 8) v = (sum - dc) / static_cast<double>(npoints);
+                else v = static_cast<T>(fma(sum, inv, -dc * inv));
+            }
+            __builtin_nontemporal_store(v, yc + j);
+        }
+        return;
+    }
     if (out0 >= mid && out0 + kMaTile <= hi) {  // interior tile: every output has its full window
         // Output i of a thread sits kThreads = 16 chunks further on than output i - 1, so all four LDS addresses move by
         // constants: they are computed once and the loop body is reads at immediate offsets plus the arithmetic (left to
@@ -1482,12 +1515,18 @@ int launch_fir_os_segment(const float *x, float *y, size_t channels, size_t n, c
 
 namespace {
 template <typename T>
-int launch_moving_average_t(const T *x, T *y, size_t channels, size_t n, int npoints, hipStream_t s) {
+int launch_moving_average_t(const T *x, T *y, size_t channels, size_t n, int npoints, hipStream_t s, unsigned period = 0) {
     if (npoints > 8192) return fail(DSP_GPU_EUNSUPPORTED, "moving average: npoints %d > 8192", npoints);
-    for (; channels > kMaxGridY; channels -= kMaxGridY, x += kMaxGridY * n, y += kMaxGridY * n)  // grid.y is 16 bits
-        if (int rc = launch_moving_average_t<T>(x, y, kMaxGridY, n, npoints, s)) return rc;
     constexpr int kVec = Smp<T>::kVec;
     const int window = 2 * (npoints / 2) + 1;
+    // Many short channels: as one signal of channels * n samples in full tiles (PERIODIC above).  From 1,048,576 x 1,024 samples
+    // (0.53 of HBM with a workgroup per channel) down to 64-sample channels (0.06): scripts/mavg_shapes.py.
+    // DSP_GPU_MAVG_NO_FLATTEN=1 (A/B runs, tests) keeps a workgroup per channel.
+    if (period == 0 && channels >= 2 && n <= 2048 && static_cast<size_t>(window) <= n && channels * n / 4096 < 0x7fffffffull &&
+        !getenv("DSP_GPU_MAVG_NO_FLATTEN"))
+        return launch_moving_average_t<T>(x, y, 1, channels * n, npoints, s, static_cast<unsigned>(n));
+    for (; channels > kMaxGridY; channels -= kMaxGridY, x += kMaxGridY * n, y += kMaxGridY * n)  // grid.y is 16 bits
+        if (int rc = launch_moving_average_t<T>(x, y, kMaxGridY, n, npoints, s)) return rc;
     // outputs per thread: the full 16 unless the whole channel fits a smaller tile (many short channels would
     // otherwise stage and scan mostly padding)
     int per = kMaPerMax;
@@ -1509,8 +1548,10 @@ int launch_moving_average_t(const T *x, T *y, size_t channels, size_t n, int npo
     const int ld_mode = [] { const char *e = getenv("DSP_GPU_MAVG_LOADS"); return e ? atoi(e) : 1; }();
     const int halo = ((window + 15) / 16) * 16 + 16;
     const bool aligned = (n % kVec == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0);
-    void (*kern)(const T *, T *, size_t, int, int, int, int, int, double, int, int) = nullptr;
-#define DSPGPU_MA_PICK(PER) kern = aligned ? moving_average_kernel<true, PER, T> : moving_average_kernel<false, PER, T>
+    void (*kern)(const T *, T *, size_t, int, int, int, int, int, double, int, int, unsigned) = nullptr;
+#define DSPGPU_MA_PICK(PER)                                                                                              \
+    kern = period ? (aligned ? moving_average_kernel<true, PER, T, true> : moving_average_kernel<false, PER, T, true>)  \
+                  : (aligned ? moving_average_kernel<true, PER, T> : moving_average_kernel<false, PER, T>)
     switch (per) {
     case 1: DSPGPU_MA_PICK(1); break;
     case 2: DSPGPU_MA_PICK(2); break;
@@ -1528,7 +1569,7 @@ int launch_moving_average_t(const T *x, T *y, size_t channels, size_t n, int npo
     // one-tile workgroups overlap.
     const char *seq_env = getenv("DSP_GPU_MAVG_SEQ");
     const bool seq_on = seq_env && seq_env[0] == '1';
-    if (seq_on && aligned && per == kMaPerMax && window + kVec <= tile / 2) {
+    if (seq_on && !period && aligned && per == kMaPerMax && window + kVec <= tile / 2) {
         const long long mid = npoints / 2;
         const long long lo = (mid + kVec + tile - 1) / tile;  // first tile whose staged span starts inside the channel
         // last tile t with t*tile - mid - (kVec-1) + span <= n (the span ends inside) and (t+1)*tile <= n - mid (full windows)
@@ -1545,11 +1586,11 @@ int launch_moving_average_t(const T *x, T *y, size_t channels, size_t n, int npo
             hipLaunchKernelGGL(kseq, dim3(runs, channels), dim3(kThreads), lds_seq, s, x, y, n, npoints, span, static_cast<int>(lo), tile_n, run);
             if (int rc = check_launch("moving_average_seq_kernel")) return rc;
             const size_t edge = blocks - static_cast<size_t>(tile_n);
-            if (edge) hipLaunchKernelGGL(kern, dim3(edge, channels), dim3(kThreads), lds_bytes, s, x, y, n, npoints, span, cpt, static_cast<int>(lo), tile_n, inv, ld_mode, halo);
+            if (edge) hipLaunchKernelGGL(kern, dim3(edge, channels), dim3(kThreads), lds_bytes, s, x, y, n, npoints, span, cpt, static_cast<int>(lo), tile_n, inv, ld_mode, halo, 0u);
             return check_launch("moving_average_kernel (edge tiles)");
         }
     }
-    hipLaunchKernelGGL(kern, dim3(blocks, channels), dim3(kThreads), lds_bytes, s, x, y, n, npoints, span, cpt, 0, 0, inv, ld_mode, halo);
+    hipLaunchKernelGGL(kern, dim3(blocks, channels), dim3(kThreads), lds_bytes, s, x, y, n, npoints, span, cpt, 0, 0, inv, ld_mode, halo, period);
     return check_launch("moving_average_kernel");
 }
 }  // namespace

@@ -487,3 +487,38 @@ def test_moving_average_tile_edge_shapes(ops, dev, orc):
             x32 = x.astype(np.float32)
             got = ops.moving_average(torch.from_numpy(x32).to(dev), pts).cpu().numpy()
             assert rel_l2(got, orc.moving_average(x32.astype(np.float64), pts)) <= 2e-6, ("float", n, pts)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [17, 64, 100, 333, 1000, 1024, 2047, 2048])
+def test_moving_average_many_short_channels(ops, dev, orc, n, monkeypatch):
+    """Many short channels run as one signal of channels * n samples in full tiles (fir_kernels.hip, PERIODIC): tiles that
+    start and end inside channels, channel lengths that are not multiples of four, windows of both parities up to the channel
+    length, exact zeros at every channel's edges, nothing written around the batch; against the oracle and against the
+    one-workgroup-per-channel path (DSP_GPU_MAVG_NO_FLATTEN=1), both sample types."""
+    import torch
+    rng = np.random.default_rng(n)
+    channels = 3 * 4096 // n + 5
+    x = rng.standard_normal((channels, n)) + 0.5
+    for pts in sorted({1, 2, 3, 8, 15, 16, min(255, n), min(256, n - 1), n - 2, n - 1, n}):
+        if pts < 1:
+            continue
+        want = orc.moving_average(x, pts)
+        mid = pts // 2
+        for f64 in (True, False):
+            xs = x if f64 else x.astype(np.float32)
+            fn = ops.moving_average_f64 if f64 else ops.moving_average
+            guard = torch.full((channels + 2, n), 7.0, device=dev, dtype=torch.float64 if f64 else torch.float32)
+            fn(torch.from_numpy(xs).to(dev), pts, out=guard[1:-1])
+            g = guard.cpu().numpy()
+            assert (g[0] == 7).all() and (g[-1] == 7).all(), (n, pts, f64)
+            got = g[1:-1]
+            ref = want if f64 else orc.moving_average(xs.astype(np.float64), pts)
+            assert rel_l2(got, ref) <= (1e-11 if f64 else 2e-6), (n, pts, f64)
+            if 2 * mid + 1 <= n:
+                assert not got[:, :mid].any() and not got[:, n - mid:].any(), (n, pts, f64)
+            monkeypatch.setenv("DSP_GPU_MAVG_NO_FLATTEN", "1")
+            other = fn(torch.from_numpy(xs).to(dev), pts).cpu().numpy()
+            monkeypatch.delenv("DSP_GPU_MAVG_NO_FLATTEN")
+            assert rel_l2(got, other) <= (1e-12 if f64 else 5e-7), (n, pts, f64)  # (prefix sums with another origin)
+
