@@ -499,6 +499,13 @@ static int convolve_impl(const char *who, const float *x, float *y, size_t chann
         mode = os_wanted ? DSP_GPU_CONV_OVERLAP_SAVE : DSP_GPU_CONV_DIRECT;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t bytes = channels * n * sizeof(float);
+    if (!history && n < static_cast<size_t>(ntaps)) {
+        // one-shot call on channels no longer than the filter's order: no output has a full window behind it, all stay zero
+        // (filter.h:126,133) -- not worth 511 taps of arithmetic per sample
+        if (mem == DSP_GPU_MEM_HOST) std::memset(y, 0, bytes);
+        else DSPGPU_HIP(hipMemsetAsync(y, 0, bytes, s));
+        return DSP_GPU_OK;
+    }
     if (mem == DSP_GPU_MEM_HOST && !history) {
         // one-shot filters: channels are independent, so the batch is pipelined in chunks of channels (mode is resolved
         // above: every chunk filters the same way)
@@ -632,6 +639,11 @@ int dsp_gpu_convolve_f64(const double *x, double *y, size_t channels, size_t n, 
     const size_t bytes = channels * n * sizeof(double);
     if (device_overlap(x, y, bytes, mem)) return fail(DSP_GPU_EINVAL, "%s: x and y overlap (the filter is not in-place on device buffers)", who);
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (n < static_cast<size_t>(ntaps)) {  // no output has a full window behind it: all stay zero (filter.h:126,133)
+        if (mem == DSP_GPU_MEM_HOST) std::memset(y, 0, bytes);
+        else DSPGPU_HIP(hipMemsetAsync(y, 0, bytes, s));
+        return DSP_GPU_OK;
+    }
     auto run = [=](const double *dx, double *dy, size_t count) -> int {
         LeaseGuard te{TapLease{}, s};
         if (int rc = acquire_taps(reinterpret_cast<const float *>(taps), 2 * ntaps, 0, s, &te.lease)) return rc;

@@ -127,6 +127,29 @@ DSP_DEV void run_rowv(T *row, double (&xh)[P], double (&vh)[P], const C &co) {
     }
 }
 
+// `count` samples of a 16-byte aligned row: whole 16-byte groups first, the remainder one by one (a channel's last, partial tile).
+template <int P, bool STORE, int ARITH = IIR_ARITH_FMA, typename T, typename C>
+DSP_DEV void run_row_count(T *row, int count, double (&xh)[P], double (&vh)[P], const C &co) {
+    using V = typename Smp<T>::vec;
+    constexpr int kVec = Smp<T>::kVec;
+    int i = 0;
+#pragma unroll 1
+    for (; i + kVec <= count; i += kVec) {
+        V q = *reinterpret_cast<const V *>(row + i);
+#pragma unroll
+        for (int k = 0; k < kVec; ++k) {
+            const T out = iir_step_out<P, ARITH, STORE>(static_cast<T>(q[k]), xh, vh, co);
+            if (STORE) q[k] = out;
+        }
+        if (STORE) *reinterpret_cast<V *>(row + i) = q;
+    }
+#pragma unroll 1
+    for (; i < count; ++i) {
+        const T out = iir_step_out<P, ARITH, STORE>(row[i], xh, vh, co);
+        if (STORE) row[i] = out;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // batch: one lane per channel.  A wave owns 64 channels and walks time in tiles of 512-byte rows (128 floats / 64
 // doubles) staged through a padded LDS tile, so HBM sees 512-byte runs per channel while every lane walks its own
@@ -158,20 +181,31 @@ DSP_DEV void batch_load(const T *__restrict__ x, size_t channels, size_t n, size
         for (int it = 0; it < BT::kIters; ++it) pre[it] = load_stream<T>(p + it * step);
         return;
     }
+    // a ragged tile (the last channels of the batch, the last samples of the channels): no branch around any load -- a group
+    // or sample outside is aimed at the last one inside its row (the batch's last row) and zeroed afterwards, so that all the
+    // tile's loads are in flight together.  (Aimed at x[0] they would all queue for one cache line: 10,000-sample rows 0.46 ->
+    // 0.34 of HBM.)
+    if (al) {  // n is a multiple of the group: a group lies wholly inside its row or wholly outside
+#pragma unroll
+        for (int it = 0; it < BT::kIters; ++it) {
+            const size_t ch = ch0 + it * BT::kRowsPerIter + lane / BT::kLanesPerRow;
+            const size_t g = t0 + (lane % BT::kLanesPerRow) * BT::kVec;
+            const bool ok = ch < channels && g < n;
+            const V v = load_stream<T>(x + (ch < channels ? ch : channels - 1) * n + (g < n ? g : n - BT::kVec));
+            pre[it] = ok ? v : V(0);
+        }
+        return;
+    }
 #pragma unroll
     for (int it = 0; it < BT::kIters; ++it) {
         const size_t ch = ch0 + it * BT::kRowsPerIter + lane / BT::kLanesPerRow;
         const size_t g = t0 + (lane % BT::kLanesPerRow) * BT::kVec;
-        V v = V(0);
-        if (ch < channels) {
-            const T *p = x + ch * n + g;
-            if (al && g + BT::kVec - 1 < n) {
-                v = load_stream<T>(p);
-            } else {
+        V v;
 #pragma unroll
-                for (int k = 0; k < BT::kVec; ++k)
-                    if (g + k < n) v[k] = p[k];
-            }
+        for (int k = 0; k < BT::kVec; ++k) {
+            const bool ok = ch < channels && g + k < n;
+            const T e = x[(ch < channels ? ch : channels - 1) * n + (g + k < n ? g + k : n - 1)];
+            v[k] = ok ? e : T(0);
         }
         pre[it] = v;
     }
@@ -232,7 +266,7 @@ __global__ __launch_bounds__(kWave) void iir_batch_kernel(const T *__restrict__ 
         if (live) {
             T *row = tile + lane * kBtPad;
             if (t0 + kBt <= n) run_rowv<P, kBt, true, ARITH>(row, xh, vh, co);
-            else run_row_partial<P, true, ARITH>(row, static_cast<int>(n - t0), xh, vh, co);
+            else run_row_count<P, true, ARITH>(row, static_cast<int>(n - t0), xh, vh, co);
         }
         __syncthreads();
         if (al && ch0 + kWave <= channels && t0 + kBt <= n) {  // full tile: LDS reads 16 bytes at a time, no bounds tests
