@@ -522,3 +522,32 @@ def test_moving_average_many_short_channels(ops, dev, orc, n, monkeypatch):
             monkeypatch.delenv("DSP_GPU_MAVG_NO_FLATTEN")
             assert rel_l2(got, other) <= (1e-12 if f64 else 5e-7), (n, pts, f64)  # (prefix sums with another origin)
 
+
+
+@pytest.mark.gpu
+def test_channels_shorter_than_the_filter_are_zero(ops, dev):
+    """One-shot calls on channels of fewer samples than taps: no output has a full window behind it, all stay zero
+    (filter.h:126,133) -- the library answers with a memset; every mode, both sample types, device and host pointers, the
+    output buffer pre-filled, nothing written around it."""
+    import torch
+    rng = np.random.default_rng(5)
+    h = rng.standard_normal(511)
+    for n in (1, 64, 510):
+        x = rng.standard_normal((9, n)).astype(np.float32)
+        for mode in ("direct", "overlap_save", "auto"):
+            guard = torch.full((11, n), 3.0, device=dev)
+            ops.convolve(torch.from_numpy(x).to(dev), h, mode, out=guard[1:-1])
+            g = guard.cpu().numpy()
+            assert (g[0] == 3).all() and (g[-1] == 3).all() and not g[1:-1].any(), (n, mode)
+            assert not ops.convolve(x, h, mode).any(), (n, mode)  # host pointers
+        guard = torch.full((11, n), 3.0, device=dev, dtype=torch.float64)
+        ops.convolve_f64(torch.from_numpy(x.astype(np.float64)).to(dev), h, out=guard[1:-1])
+        g = guard.cpu().numpy()
+        assert (g[0] == 3).all() and (g[-1] == 3).all() and not g[1:-1].any(), n
+        assert not ops.convolve_f64(x.astype(np.float64), h).any(), n
+    # one sample more and the last output is the first with a full window
+    x = rng.standard_normal((2, 511)).astype(np.float32)
+    got = ops.convolve(torch.from_numpy(x).to(dev), h, "direct").cpu().numpy()
+    assert not got[:, :510].any()
+    want = (x.astype(np.float64)[:, ::-1] * h.astype(np.float32).astype(np.float64)).sum(axis=1)
+    assert np.allclose(got[:, 510], want, rtol=2e-5, atol=2e-5)
