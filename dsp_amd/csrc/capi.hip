@@ -483,7 +483,7 @@ static int convolve_impl(const char *who, const float *x, float *y, size_t chann
         return fail(DSP_GPU_EUNSUPPORTED, "%s: the VALU direct form has no streaming variant", who);
     // a 4096-point block holds 2049 taps, a 16384-point block 8193; longer filters run partitioned (8192-tap segments
     // on 16384-point blocks, one overlap-save pass each, accumulated) in the one-shot form
-    const bool os_wanted = mode == DSP_GPU_CONV_OVERLAP_SAVE || (mode == DSP_GPU_CONV_AUTO && (ntaps > 4096 || (ntaps >= 64 && n >= 256) || (ntaps >= 40 && n >= 65536)));  // scripts/fir_crossover.py, fir_short_channels.py
+    const bool os_wanted = mode == DSP_GPU_CONV_OVERLAP_SAVE || (mode == DSP_GPU_CONV_AUTO && (ntaps > 4096 || (ntaps >= 64 && n >= 256) || (ntaps >= 40 && n >= 262144)));  // scripts/fir_crossover.py, fir_short_channels.py
                                                                    // (long channels: the wave kernel at hop 3840 runs 1.6 ms on 1,024 x 2^20 at any
                                                                    // of these lengths, the direct kernel 1.60 at 31 taps and 1.93 at 63)
     const bool partitioned = ntaps > kSegmentTaps + 1 && !history && os_wanted;

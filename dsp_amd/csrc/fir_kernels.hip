@@ -53,11 +53,16 @@ constexpr int kFirOutPerWg = kFirWaves * kFirAcc * kFirTile * kFirPasses;  // 81
 // Long channels: one slot, S = 8192 outputs of channel blockIdx.y starting at blockIdx.x * 8192.  Channels of at most
 // 4096 samples: S = n rounded up to 1024 (what one wave covers per pass) and the workgroup takes 8192 / S channels at
 // once, each with its own history in front -- otherwise three of the four waves would idle on a 1024-sample channel.
-template <bool ALIGNED, bool MULTI>  // MULTI: more than one slot (kept apart: the slot arithmetic cost the long-channel path 3 %)
+// PERIODIC (one-shot calls on many channels shorter than a few workgroups' worth): the channels lie one behind the other in
+// memory, and an output with a full window behind it never reaches across its channel's start, so the batch is filtered as ONE
+// signal of channels * period samples (n is that product, one "channel") and the outputs whose position inside their channel
+// is below the filter's order -- the ones that would have seen the previous channel's tail -- are zeroed as filter.h:126,133
+// asks anyway.  No slot rounded up to 1,024 outputs, no last workgroup of a 10,000-sample channel that is three quarters empty.
+template <bool ALIGNED, bool MULTI, bool PERIODIC = false>  // MULTI: more than one slot (kept apart: the slot arithmetic cost the long-channel path 3 %)
 __global__ __launch_bounds__(kFirThreads) void fir_direct_kernel(const float *__restrict__ x, float *__restrict__ y,
                                                                   size_t n, size_t channels, const float *__restrict__ taps,
                                                                   int ntaps, int Q, int slots, int S,
-                                                                  const float *__restrict__ prev, int zero_head) {
+                                                                  const float *__restrict__ prev, int zero_head, unsigned period) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int hist = 16 * (Q - 1);
     const int slot_len = hist + S;
@@ -207,8 +212,17 @@ __global__ __launch_bounds__(kFirThreads) void fir_direct_kernel(const float *__
             const long long j = chunk0 + local + static_cast<long long>(t) * kFirTile + 16 * r + 4 * kq;
             if (j >= nn) continue;
             float o[4];
+            if constexpr (PERIODIC) {  // (the host has checked that channels * period fits 32 bits)
+                unsigned jm = static_cast<unsigned>(j) % period;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) o[i] = (j + i >= order) ? acc[t][i] : 0.0f;  // filter.h:133: first M outputs stay 0
+                for (int i = 0; i < 4; ++i) {
+                    o[i] = jm >= static_cast<unsigned>(order) ? acc[t][i] : 0.0f;
+                    if (++jm == period) jm = 0;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i] = (j + i >= order) ? acc[t][i] : 0.0f;  // filter.h:133: first M outputs stay 0
+            }
             if (ALIGNED && j + 3 < nn) {
                 *reinterpret_cast<float4 *>(yc + j) = make_float4(o[0], o[1], o[2], o[3]);
             } else {
@@ -1304,6 +1318,22 @@ int launch_fir_direct(const float *x, float *y, size_t channels, size_t n, const
                       const float *hist, int zero_head, hipStream_t s) {
     const int order = ntaps - 1;
     const int Q = (order + 15) / 16 + 1;
+    // One-shot calls on many channels of less than a few workgroups' worth of samples: as one signal (PERIODIC above).
+    // 7 taps, 2^28 samples: 4,194,304 x 64 samples 0.07 -> 0.60-0.64 of HBM, 1,048,576 x 256 0.25 -> 0.68, 26,843 x 10,000 0.54 -> 0.67
+    // (scripts/fir_short_filters.py, profiles/r03_fir_short_filters.txt).
+    // DSP_GPU_FIR_NO_FLATTEN=1 (A/B runs, tests) keeps the channels apart.
+    if (!hist && zero_head == order && channels >= 2 && n >= static_cast<size_t>(ntaps) && n < 65536 &&
+        channels * n < 0xffffffffull && !getenv("DSP_GPU_FIR_NO_FLATTEN")) {
+        const size_t total = channels * n;
+        const bool al = (total % 4 == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0) && (reinterpret_cast<uintptr_t>(y) % 16 == 0);
+        auto kern = al ? fir_direct_kernel<true, false, true> : fir_direct_kernel<false, false, true>;
+        const size_t lds = (static_cast<size_t>(16 * (Q - 1) + kFirOutPerWg) + 4u * (16 * Q + 16)) * sizeof(float);
+        if (lds > 64 * 1024)
+            if (int rc = allow_full_lds(reinterpret_cast<const void *>(kern))) return rc;
+        hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>((total + kFirOutPerWg - 1) / kFirOutPerWg), 1), dim3(kFirThreads), lds, s, x, y,
+                           total, size_t{1}, d_taps, ntaps, Q, 1, kFirOutPerWg, nullptr, zero_head, static_cast<unsigned>(n));
+        return check_launch("fir_direct_kernel<periodic>");
+    }
     // channels of at most 4096 samples: several to a workgroup (slots), each rounded up to the 1024 outputs of a wave-pass
     const int quantum = kFirAcc * kFirTile;
     const int S = n * 2 <= static_cast<size_t>(kFirOutPerWg) ? static_cast<int>((n + quantum - 1) / quantum) * quantum : kFirOutPerWg;
@@ -1324,7 +1354,7 @@ int launch_fir_direct(const float *x, float *y, size_t channels, size_t n, const
     if (lds_bytes > 64 * 1024)
         if (int rc = allow_full_lds(reinterpret_cast<const void *>(kern))) return rc;
     hipLaunchKernelGGL(kern, dim3(blocks, groups), dim3(kFirThreads), lds_bytes, s, x, y, n, channels, d_taps, ntaps, Q, slots, S,
-                       hist, zero_head);
+                       hist, zero_head, 0u);
     return check_launch("fir_direct_kernel");
 }
 

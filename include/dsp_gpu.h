@@ -58,7 +58,7 @@ extern "C" {
 
 /* convolution mode (the reference's dsp::Domain, dsp.h:14: Time -> DIRECT, Frequency -> OVERLAP_SAVE) */
 #define DSP_GPU_CONV_AUTO         0 /* OVERLAP_SAVE from 64 taps up (channels of >= 256 samples; from 40 taps on channels of
-                                      >= 65,536 samples) and above 4096 taps, else DIRECT; overlap-save results carry the FFT's error (1e-5*12), not 1e-6 */
+                                      >= 262,144 samples) and above 4096 taps, else DIRECT; overlap-save results carry the FFT's error (1e-5*12), not 1e-6 */
 #define DSP_GPU_CONV_DIRECT       1
 #define DSP_GPU_CONV_OVERLAP_SAVE 2
 #define DSP_GPU_CONV_DIRECT_VALU  3 /* direct form on the vector ALU instead of the matrix cores: the A/B partner

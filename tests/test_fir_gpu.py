@@ -551,3 +551,30 @@ def test_channels_shorter_than_the_filter_are_zero(ops, dev):
     assert not got[:, :510].any()
     want = (x.astype(np.float64)[:, ::-1] * h.astype(np.float32).astype(np.float64)).sum(axis=1)
     assert np.allclose(got[:, 510], want, rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("channels,n,ntaps", [(700, 64, 7), (333, 100, 31), (64, 256, 63), (50, 1000, 511), (9, 10000, 129),
+                                              (3, 65535, 33), (5, 4099, 4096), (40, 511, 511)])
+def test_direct_many_channels_as_one_signal(ops, dev, orc, channels, n, ntaps, monkeypatch):
+    """One-shot direct FIR on many channels runs them as one signal (fir_kernels.hip, PERIODIC): the first ntaps - 1 outputs of
+    every channel are exact zeros, nothing leaks across channel borders (each channel also filtered on its own), totals that
+    are not multiples of four, nothing written around the batch; against the oracle and the per-channel path."""
+    import torch
+    rng = np.random.default_rng(channels + n + ntaps)
+    h = rng.standard_normal(ntaps) / np.sqrt(ntaps)
+    x = (rng.standard_normal((channels, n)) * 3 + 1).astype(np.float32)
+    want = orc.fir(x.astype(np.float64), h.astype(np.float32).astype(np.float64))
+    guard = torch.full((channels + 2, n), 9.0, device=dev)
+    ops.convolve(torch.from_numpy(x).to(dev), h, "direct", out=guard[1:-1])
+    g = guard.cpu().numpy()
+    assert (g[0] == 9).all() and (g[-1] == 9).all()
+    got = g[1:-1]
+    assert rel_l2(got, want) <= DIRECT_TOL
+    assert not got[:, : ntaps - 1].any()
+    for c in (0, channels // 2, channels - 1):  # a channel alone: no neighbour to leak from
+        alone = ops.convolve(torch.from_numpy(x[c:c + 1]).to(dev), h, "direct").cpu().numpy()
+        assert rel_l2(got[c:c + 1], alone) <= 2 * DIRECT_TOL, c  # (two fp32 sums in different orders)
+    monkeypatch.setenv("DSP_GPU_FIR_NO_FLATTEN", "1")
+    other = ops.convolve(torch.from_numpy(x).to(dev), h, "direct").cpu().numpy()
+    assert rel_l2(got, other) <= 2 * DIRECT_TOL
