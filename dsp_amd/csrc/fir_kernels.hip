@@ -1392,6 +1392,20 @@ int launch_os(const float *x, float *y, size_t channels, size_t n, const c32 *d_
     const long long valid = nv > order ? nv - order : 0;
     // block 0 delivers N - order outputs, every later block L (block 0 also zero-fills y[0, order))
     auto blocks_at = [&](long long hop_v) { return valid > kOsN - order ? 1 + (valid - (kOsN - order) + hop_v - 1) / hop_v : 1ll; };
+    // One-shot calls on several channels of up to some tens of blocks each (where many pairs hold a channel's first or last
+    // block, which the wave kernel leaves to the workgroup kernel): as ONE signal of channels * n samples -- an output with a full window behind it never reaches across
+    // its channel's start -- and then zeros over the first `order` outputs of every channel but the first (filter.h:126,133; those
+    // would have seen the previous channel's tail).  Costs order / n more written bytes and buys the long-signal kernels:
+    // 32,768 x 8,192, 511 taps: 0.41 -> 0.54 of HBM, 4,096 x 65,536: 0.56 -> 0.62 (profiles/r03_fir_mid_channels.txt; channels of up to
+    // 4,096 samples lose by it: 0.59 -> 0.47, the zeros being 2-KB rows).  DSP_GPU_FIR_NO_FLATTEN=1 keeps the channels apart.
+    if (log2n == 12 && channels >= 2 && !hist && !ex.accumulate && !ex.zero_hist && !ex.edge_pairs && ex.stride == n && ex.yoff == 0 &&
+        zero_head == order && n > 4096 && n < 262144 && channels * n < 0xffffffffull && !getenv("DSP_GPU_FIR_NO_FLATTEN")) {
+        const size_t total = channels * n;
+        if (int rc = launch_os(x, y, 1, total, d_hspec, ntaps, nullptr, zero_head, OsExtra{total, 0, 0, 0, 0}, log2n, s)) return rc;
+        if (order > 0)
+            DSPGPU_HIP(hipMemset2DAsync(y + n, n * sizeof(float), 0, static_cast<size_t>(order) * sizeof(float), channels - 1, s));
+        return DSP_GPU_OK;
+    }
     // hop between blocks: N - order at most
     long long L = kOsN - order;
     // The one-wave-per-pair kernel wants a hop of whole 1-KB rows (256 samples; its 16-byte stores, the rows it shares between

@@ -578,3 +578,28 @@ def test_direct_many_channels_as_one_signal(ops, dev, orc, channels, n, ntaps, m
     monkeypatch.setenv("DSP_GPU_FIR_NO_FLATTEN", "1")
     other = ops.convolve(torch.from_numpy(x).to(dev), h, "direct").cpu().numpy()
     assert rel_l2(got, other) <= 2 * DIRECT_TOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("channels,n,ntaps", [(40, 6000, 511), (9, 10001, 129), (3, 65535, 33), (5, 4099, 2049), (17, 8192, 1023)])
+def test_overlap_save_many_channels_as_one_signal(ops, dev, orc, channels, n, ntaps, monkeypatch):
+    """One-shot overlap-save on several channels of 4,097 ... 262,143 samples runs them as one signal and then zeroes the first
+    ntaps - 1 outputs of every channel (fir_kernels.hip, launch_os): exact zeros there, nothing leaked across channel borders,
+    nothing written around the batch; against the oracle and the per-channel path (DSP_GPU_FIR_NO_FLATTEN=1)."""
+    import torch
+    rng = np.random.default_rng(channels * n + ntaps)
+    h = rng.standard_normal(ntaps) / np.sqrt(ntaps)
+    x = (rng.standard_normal((channels, n)) * 3 + 1).astype(np.float32)
+    want = orc.fir(x.astype(np.float64), h)
+    guard = torch.full((channels + 2, n), 9.0, device=dev)
+    ops.convolve(torch.from_numpy(x).to(dev), h, "overlap_save", out=guard[1:-1])
+    g = guard.cpu().numpy()
+    assert (g[0] == 9).all() and (g[-1] == 9).all()
+    got = g[1:-1]
+    assert rel_l2(got, want) <= OS_TOL
+    assert not got[:, : ntaps - 1].any()
+    for c in (0, channels // 2, channels - 1):
+        assert rel_l2(got[c], want[c]) <= OS_TOL, c
+    monkeypatch.setenv("DSP_GPU_FIR_NO_FLATTEN", "1")
+    other = ops.convolve(torch.from_numpy(x).to(dev), h, "overlap_save").cpu().numpy()
+    assert rel_l2(got, other) <= 1e-5
