@@ -17,6 +17,8 @@
 // tuned one: the double matrix pipe delivers 78 TFLOP/s, a quarter of what bounds it is LDS-free arithmetic.
 #include <algorithm>
 
+#include <cstdlib>
+
 #include "common.h"
 
 namespace dspgpu {
@@ -36,7 +38,8 @@ constexpr size_t kMaxGridY64 = 65535;
 // the reversed, zero padded taps hr[w] = h[16Q - w], w in [0, 16Q + 16).
 template <bool ALIGNED>
 __global__ __launch_bounds__(kThreads64) void fir_direct_f64_kernel(const double *__restrict__ x, double *__restrict__ y, size_t n,
-                                                                    const double *__restrict__ taps, int ntaps, int Q) {
+                                                                    const double *__restrict__ taps, int ntaps, int Q,
+                                                                    unsigned period) {  // != 0: see launch_fir_direct_f64
     extern __shared__ __attribute__((aligned(16))) double smem64[];
     const int hist = 16 * (Q - 1);
     const int xs_len = hist + kOutPerWg64;
@@ -58,8 +61,10 @@ __global__ __launch_bounds__(kThreads64) void fir_direct_f64_kernel(const double
     for (int u = tid * 2; u < xs_len; u += kThreads64 * 2) {
         const long long g = seg0 + u;
         d2 v = {0.0, 0.0};
-        if (ALIGNED && g >= 0 && g + 1 < nn) {
-            v = load_stream<double>(xc + g);
+        if (ALIGNED) {  // no branch around the load: a group outside the channel is aimed at its first sample and zeroed
+            const bool ok = g >= 0 && g + 1 < nn;
+            v = load_stream<double>(xc + (ok ? g : 0));
+            if (!ok) v = d2{0.0, 0.0};
         } else {
             if (g >= 0 && g < nn) v[0] = xc[g];
             if (g + 1 >= 0 && g + 1 < nn) v[1] = xc[g + 1];
@@ -98,8 +103,17 @@ __global__ __launch_bounds__(kThreads64) void fir_direct_f64_kernel(const double
         const long long j = chunk0 + local + static_cast<long long>(t) * kTile64 + 16 * r + 4 * kq;
         if (j >= nn) continue;
         double o[4];
+        if (period) {  // (wave-uniform) many channels as one signal: zeros by the position inside the channel
+            unsigned jm = static_cast<unsigned>(j) % period;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) o[i] = (j + i >= order) ? acc[t][i] : 0.0;  // filter.h:133: first M outputs stay 0
+            for (int i = 0; i < 4; ++i) {
+                o[i] = jm >= static_cast<unsigned>(order) ? acc[t][i] : 0.0;
+                if (++jm == period) jm = 0;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = (j + i >= order) ? acc[t][i] : 0.0;  // filter.h:133: first M outputs stay 0
+        }
         if (ALIGNED && j + 3 < nn) {
             store_stream<double>(yc + j, d2{o[0], o[1]});
             store_stream<double>(yc + j + 2, d2{o[2], o[3]});
@@ -114,6 +128,16 @@ __global__ __launch_bounds__(kThreads64) void fir_direct_f64_kernel(const double
 }  // namespace
 
 int launch_fir_direct_f64(const double *x, double *y, size_t channels, size_t n, const double *d_taps, int ntaps, hipStream_t s) {
+    // Many channels of less than a few workgroups' worth of samples run as ONE signal of channels * n samples, as in the fp32
+    // kernel (fir_kernels.hip, PERIODIC): an output with a full window behind it never reaches across its channel's start, the
+    // first ntaps - 1 outputs of every channel are zeroed by their position j mod n.  2,097,152 x 64 doubles, 7 taps: 0.04 ->
+    // 0.50 of HBM; 134,217 x 1,000, 511 taps: 0.37 -> 0.76 of the fp64 MFMA rate (scripts/fir_f64_shapes.py).  DSP_GPU_FIR_NO_FLATTEN=1 keeps the channels apart.
+    unsigned period = 0;
+    if (channels >= 2 && n >= static_cast<size_t>(ntaps) && n < 65536 && channels * n < 0xffffffffull && !getenv("DSP_GPU_FIR_NO_FLATTEN")) {
+        period = static_cast<unsigned>(n);
+        n *= channels;
+        channels = 1;
+    }
     for (; channels > kMaxGridY64; channels -= kMaxGridY64, x += kMaxGridY64 * n, y += kMaxGridY64 * n)  // grid.y is 16 bits
         if (int rc = launch_fir_direct_f64(x, y, kMaxGridY64, n, d_taps, ntaps, s)) return rc;
     const int order = ntaps - 1;
@@ -126,7 +150,7 @@ int launch_fir_direct_f64(const double *x, double *y, size_t channels, size_t n,
     if (lds_bytes > 64 * 1024)
         if (int rc = allow_full_lds(reinterpret_cast<const void *>(kern))) return rc;
     hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks), static_cast<unsigned>(channels)), dim3(kThreads64), lds_bytes, s, x,
-                       y, n, d_taps, ntaps, Q);
+                       y, n, d_taps, ntaps, Q, period);
     return check_launch("fir_direct_f64_kernel");
 }
 

@@ -157,3 +157,25 @@ def test_moving_average_kat_double(ops, dev):
     import torch
     got = ops.moving_average_f64(torch.arange(16, dtype=torch.float64, device=dev), 5).cpu().numpy()
     assert np.array_equal(got, [0, 0, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 0, 0])
+
+
+@pytest.mark.parametrize("channels,n,ntaps", [(700, 64, 7), (333, 101, 31), (50, 1000, 511), (9, 10001, 129), (3, 65535, 33)])
+def test_many_channels_as_one_signal_double(ops, dev, orc, channels, n, ntaps, monkeypatch):
+    """dsp_gpu_convolve_f64 on many channels runs them as one signal (fir_f64_kernels.hip): exact zeros over the first
+    ntaps - 1 outputs of every channel, nothing leaked across channel borders, odd totals, nothing written around the batch;
+    against the oracle and the per-channel path (DSP_GPU_FIR_NO_FLATTEN=1)."""
+    import torch
+    rng = np.random.default_rng(channels + n + ntaps)
+    h = rng.standard_normal(ntaps) / np.sqrt(ntaps)
+    x = rng.standard_normal((channels, n)) * 3 + 1
+    want = orc.fir(x, h)
+    guard = torch.full((channels + 2, n), 9.0, device=dev, dtype=torch.float64)
+    ops.convolve_f64(torch.from_numpy(x).to(dev), h, out=guard[1:-1])
+    g = guard.cpu().numpy()
+    assert (g[0] == 9).all() and (g[-1] == 9).all()
+    got = g[1:-1]
+    assert rel_l2(got, want) <= TOL64
+    assert not got[:, : ntaps - 1].any()
+    monkeypatch.setenv("DSP_GPU_FIR_NO_FLATTEN", "1")
+    other = ops.convolve_f64(torch.from_numpy(x).to(dev), h).cpu().numpy()
+    assert rel_l2(got, other) <= 2 * TOL64
