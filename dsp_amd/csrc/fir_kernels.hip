@@ -1379,6 +1379,14 @@ size_t os_wave_min_tiles() {
 // most pairs are such edge pairs and that split costs more than it gains -- 65,536 x 4,096 (one block per channel): 1.82 ms split
 // against 0.47 ms on the workgroup kernel alone; 8,192 x 32,768 (10 blocks): 0.55 / 0.49; 4,096 x 65,536 (19 blocks): 0.47 /
 // 0.53 (scripts/fir_mid_channels.py, profiles/r03_fir_mid_channels.txt).  A DSP_GPU_OS_WAVE_MIN_TILES override lifts this too.
+// zeros over the first `count` samples of `rows` rows that lie `stride` samples apart: one wave per row
+__global__ __launch_bounds__(256) void zero_heads_kernel(float *__restrict__ y, size_t stride, unsigned count, size_t rows) {
+    const size_t row = static_cast<size_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float *p = y + row * stride;
+    for (unsigned i = threadIdx.x & 63; i < count; i += 64) p[i] = 0.0f;
+}
+
 size_t os_wave_min_blocks_per_channel() {
     const char *e = getenv("DSP_GPU_OS_WAVE_MIN_TILES");
     return (e && *e) ? 1 : 14;
@@ -1396,14 +1404,18 @@ int launch_os(const float *x, float *y, size_t channels, size_t n, const c32 *d_
     // block, which the wave kernel leaves to the workgroup kernel): as ONE signal of channels * n samples -- an output with a full window behind it never reaches across
     // its channel's start -- and then zeros over the first `order` outputs of every channel but the first (filter.h:126,133; those
     // would have seen the previous channel's tail).  Costs order / n more written bytes and buys the long-signal kernels:
-    // 32,768 x 8,192, 511 taps: 0.41 -> 0.54 of HBM, 4,096 x 65,536: 0.56 -> 0.62 (profiles/r03_fir_mid_channels.txt; channels of up to
-    // 4,096 samples lose by it: 0.59 -> 0.47, the zeros being 2-KB rows).  DSP_GPU_FIR_NO_FLATTEN=1 keeps the channels apart.
+    // 511 taps, 2^28 samples: 87,381 x 3,072 0.46 -> 0.60 of HBM, 32,768 x 8,192 0.41 -> 0.62, 4,096 x 65,536 0.56 -> 0.64
+    // (profiles/r03_fir_mid_channels.txt).  DSP_GPU_FIR_NO_FLATTEN=1 keeps the channels apart.
     if (log2n == 12 && channels >= 2 && !hist && !ex.accumulate && !ex.zero_hist && !ex.edge_pairs && ex.stride == n && ex.yoff == 0 &&
-        zero_head == order && n > 4096 && n < 262144 && channels * n < 0xffffffffull && !getenv("DSP_GPU_FIR_NO_FLATTEN")) {
+        zero_head == order && n >= 1536 && n < 262144 && channels * n < 0xffffffffull && !getenv("DSP_GPU_FIR_NO_FLATTEN")) {
         const size_t total = channels * n;
         if (int rc = launch_os(x, y, 1, total, d_hspec, ntaps, nullptr, zero_head, OsExtra{total, 0, 0, 0, 0}, log2n, s)) return rc;
-        if (order > 0)
-            DSPGPU_HIP(hipMemset2DAsync(y + n, n * sizeof(float), 0, static_cast<size_t>(order) * sizeof(float), channels - 1, s));
+        if (order > 0) {  // (hipMemset2DAsync takes ~1.8 ns per row whatever its length: 120 us for 65,535 rows of 2 KB)
+            const size_t heads = channels - 1;
+            hipLaunchKernelGGL(zero_heads_kernel, dim3(static_cast<unsigned>((heads + 3) / 4)), dim3(256), 0, s, y + n, n,
+                               static_cast<unsigned>(order), heads);
+            return check_launch("zero_heads_kernel");
+        }
         return DSP_GPU_OK;
     }
     // hop between blocks: N - order at most

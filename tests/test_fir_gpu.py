@@ -581,9 +581,10 @@ def test_direct_many_channels_as_one_signal(ops, dev, orc, channels, n, ntaps, m
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("channels,n,ntaps", [(40, 6000, 511), (9, 10001, 129), (3, 65535, 33), (5, 4099, 2049), (17, 8192, 1023)])
+@pytest.mark.parametrize("channels,n,ntaps", [(40, 6000, 511), (9, 10001, 129), (3, 65535, 33), (5, 4099, 2049), (17, 8192, 1023),
+                                              (50, 3072, 511), (33, 1536, 200), (21, 2049, 1025), (12, 4096, 2049)])
 def test_overlap_save_many_channels_as_one_signal(ops, dev, orc, channels, n, ntaps, monkeypatch):
-    """One-shot overlap-save on several channels of 4,097 ... 262,143 samples runs them as one signal and then zeroes the first
+    """One-shot overlap-save on several channels of 1,536 ... 262,143 samples runs them as one signal and then zeroes the first
     ntaps - 1 outputs of every channel (fir_kernels.hip, launch_os): exact zeros there, nothing leaked across channel borders,
     nothing written around the batch; against the oracle and the per-channel path (DSP_GPU_FIR_NO_FLATTEN=1)."""
     import torch
