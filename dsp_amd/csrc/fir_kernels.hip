@@ -51,7 +51,7 @@ constexpr int kFirOutPerWg = kFirWaves * kFirAcc * kFirTile * kFirPasses;  // 81
 // LDS: `slots` input segments float xs[hist + S] (slots * S = kFirOutPerWg) followed by 4 shifted, reversed, zero
 // padded copies of the taps, each taps_len = 16*Q + 16 floats:  copy s holds As[w] = h[16Q - s - w].
 // Long channels: one slot, S = 8192 outputs of channel blockIdx.y starting at blockIdx.x * 8192.  Channels of at most
-// 4096 samples: S = n rounded up to 1024 (what one wave covers per pass) and the workgroup takes 8192 / S channels at
+// 4096 samples: S = n rounded up to 256 (one tile; until late round 3: 1024, what one wave covers per pass) and the workgroup takes 8192 / S channels at
 // once, each with its own history in front -- otherwise three of the four waves would idle on a 1024-sample channel.
 // PERIODIC (one-shot calls on many channels shorter than a few workgroups' worth): the channels lie one behind the other in
 // memory, and an output with a full window behind it never reaches across its channel's start, so the batch is filtered as ONE
@@ -169,15 +169,29 @@ __global__ __launch_bounds__(kFirThreads) void fir_direct_kernel(const float *__
 #pragma unroll 1
     for (int pass = 0; pass < kFirPasses; ++pass) {
         const int tile0 = (pass * kFirWaves + wave) * kFirAcc;  // first of this wave's tiles in the workgroup's 8192 outputs
-        const int k = MULTI ? tile0 * kFirTile / S : 0;         // its slot (S is a multiple of the 1024 outputs of a wave-pass)
-        const int local = tile0 * kFirTile - k * S;             // first output inside the slot
-        const size_t ch = ch0 + k;
+        // MULTI: S is a multiple of one tile's 256 outputs, so each of the wave's four tiles has a slot and a place in it of its own
+        // (a streamed 256-sample chunk is one tile: rounded up to the 1,024 outputs of a wave-pass it cost four times the work)
+        const int k = 0;
+        const int local = tile0 * kFirTile;  // (!MULTI) first output inside the workgroup's chunk
+        int kt[kFirAcc], lt[kFirAcc];
+        bool live[kFirAcc];
+        const float *bp[kFirAcc];
         if (MULTI) {
-            if (k >= slots || ch >= channels || local >= nn) continue;  // wave-uniform
+            bool any = false;
+#pragma unroll
+            for (int t = 0; t < kFirAcc; ++t) {
+                const int o = (tile0 + t) * kFirTile;
+                kt[t] = o / S;
+                lt[t] = o - kt[t] * S;
+                live[t] = kt[t] < slots && ch0 + kt[t] < channels && lt[t] < nn;  // wave-uniform
+                any = any || live[t];
+                bp[t] = xs + (live[t] ? kt[t] * slot_len + lt[t] : 0) + hist + 16 * r + 4 * kq;  // (a dead tile reads slot 0 and stores nothing)
+            }
+            if (!any) continue;
         } else if (chunk0 + local >= nn) {
             break;  // wave-uniform
         }
-        float *yc = y + ch * n;
+        float *yc = y + ch0 * n;
         const float *b_ptr = xs + k * slot_len + hist + local + 16 * r + 4 * kq;
         // The taps are summed in segments of kFirSeg blocks (256 taps) with a fresh accumulator each,
         // so the fp32 rounding of a long filter grows like a blocked sum, not like one long chain.
@@ -195,7 +209,7 @@ __global__ __launch_bounds__(kFirThreads) void fir_direct_kernel(const float *__
                 f32x4 b4[kFirAcc];
 #pragma unroll
                 for (int t = 0; t < kFirAcc; ++t)
-                    b4[t] = *reinterpret_cast<const f32x4 *>(b_ptr + t * kFirTile - 16 * q);
+                    b4[t] = *reinterpret_cast<const f32x4 *>((MULTI ? bp[t] : b_ptr + t * kFirTile) - 16 * q);
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
@@ -209,7 +223,10 @@ __global__ __launch_bounds__(kFirThreads) void fir_direct_kernel(const float *__
         // D: column = lane & 15, rows 4*(lane >> 4) + i  ->  y[j0 + 16*col + 4*(lane>>4) + i]
 #pragma unroll
         for (int t = 0; t < kFirAcc; ++t) {
-            const long long j = chunk0 + local + static_cast<long long>(t) * kFirTile + 16 * r + 4 * kq;
+            if (MULTI && !live[t]) continue;
+            if (MULTI) yc = y + (ch0 + kt[t]) * n;
+            const long long j = MULTI ? static_cast<long long>(lt[t]) + 16 * r + 4 * kq
+                                      : chunk0 + local + static_cast<long long>(t) * kFirTile + 16 * r + 4 * kq;
             if (j >= nn) continue;
             float o[4];
             if constexpr (PERIODIC) {  // (the host has checked that channels * period fits 32 bits)
@@ -1334,8 +1351,8 @@ int launch_fir_direct(const float *x, float *y, size_t channels, size_t n, const
                            total, size_t{1}, d_taps, ntaps, Q, 1, kFirOutPerWg, nullptr, zero_head, static_cast<unsigned>(n));
         return check_launch("fir_direct_kernel<periodic>");
     }
-    // channels of at most 4096 samples: several to a workgroup (slots), each rounded up to the 1024 outputs of a wave-pass
-    const int quantum = kFirAcc * kFirTile;
+    // channels of at most 4096 samples: several to a workgroup (slots), each rounded up to one tile's 256 outputs
+    const int quantum = kFirTile;  // (one tile; until late round 3 the 1,024 outputs of a wave-pass)
     const int S = n * 2 <= static_cast<size_t>(kFirOutPerWg) ? static_cast<int>((n + quantum - 1) / quantum) * quantum : kFirOutPerWg;
     int slots = kFirOutPerWg / S;
     // every slot carries its own history: keep the workgroup's LDS near 80 KB (two workgroups per CU) for long filters
