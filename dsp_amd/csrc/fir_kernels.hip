@@ -1592,11 +1592,14 @@ int launch_moving_average_t(const T *x, T *y, size_t channels, size_t n, int npo
     if (npoints > 8192) return fail(DSP_GPU_EUNSUPPORTED, "moving average: npoints %d > 8192", npoints);
     constexpr int kVec = Smp<T>::kVec;
     const int window = 2 * (npoints / 2) + 1;
-    // Many short channels: as one signal of channels * n samples in full tiles (PERIODIC above).  From 1,048,576 x 1,024 samples
-    // (0.53 of HBM with a workgroup per channel) down to 64-sample channels (0.06): scripts/mavg_shapes.py.
+    // Many short channels: as one signal of channels * n samples in full tiles (PERIODIC above).  2^29 samples, 5 / 511 points
+    // (scripts/mavg_mid_channels.py, profiles/r03_mavg_shapes.txt): 512-sample channels 0.37 / 0.41 -> 0.52 / 0.72 of HBM, 1,024:
+    // 0.52 / 0.60 -> 0.60 / 0.67; equal at 1,536, and from there the per-channel tiles (one, two, four or eight outputs per thread
+    // fewer) win: 2,048: 0.57 / 0.69 against 0.52 / 0.60.  Also channels that leave their second 4096-output tile mostly empty:
+    // 4,500 samples 0.48 / 0.44 -> 0.61, 5,000: 0.53 / 0.48 -> 0.61, 6,000: 0.59 / 0.56 -> 0.61 / 0.59 (three tiles and more: not).
     // DSP_GPU_MAVG_NO_FLATTEN=1 (A/B runs, tests) keeps a workgroup per channel.
-    if (period == 0 && channels >= 2 && n <= 2048 && static_cast<size_t>(window) <= n && channels * n / 4096 < 0x7fffffffull &&
-        !getenv("DSP_GPU_MAVG_NO_FLATTEN"))
+    if (period == 0 && channels >= 2 && (n < 1536 || (n > 4096 && n <= 6144)) && static_cast<size_t>(window) <= n &&
+        channels * n / 4096 < 0x7fffffffull && !getenv("DSP_GPU_MAVG_NO_FLATTEN"))
         return launch_moving_average_t<T>(x, y, 1, channels * n, npoints, s, static_cast<unsigned>(n));
     for (; channels > kMaxGridY; channels -= kMaxGridY, x += kMaxGridY * n, y += kMaxGridY * n)  // grid.y is 16 bits
         if (int rc = launch_moving_average_t<T>(x, y, kMaxGridY, n, npoints, s)) return rc;

@@ -490,7 +490,7 @@ def test_moving_average_tile_edge_shapes(ops, dev, orc):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n", [17, 64, 100, 333, 1000, 1024, 2047, 2048])
+@pytest.mark.parametrize("n", [17, 64, 100, 333, 1000, 1024, 1535, 2048, 4500, 6144])
 def test_moving_average_many_short_channels(ops, dev, orc, n, monkeypatch):
     """Many short channels run as one signal of channels * n samples in full tiles (fir_kernels.hip, PERIODIC): tiles that
     start and end inside channels, channel lengths that are not multiples of four, windows of both parities up to the channel
