@@ -64,12 +64,40 @@ __global__ __launch_bounds__(64) void copy_rows_pipelined(const float* __restric
     }
 }
 
+// ROWS rows per wave (one lane per row would use only ROWS of the 64 lanes), SEG samples per row and tile: fewer, longer streams
+template <int SEG, int ROWS>
+__global__ __launch_bounds__(64) void copy_rows_few(const float* __restrict__ x, float* __restrict__ y, size_t n, size_t chunk, size_t groups) {
+    extern __shared__ float dummy[];
+    const int lane = threadIdx.x;
+    const size_t group = (size_t)(blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+    if (group >= groups) return;
+    constexpr int LPR = SEG / 4 < 64 ? SEG / 4 : 64, RPI = 64 / LPR, IPR = SEG / 4 / LPR, ITERS = ROWS / RPI * IPR;
+    if (lane == 0 && n == 1) dummy[0] = 0;
+    for (size_t t0 = 0; t0 < n; t0 += SEG) {
+        for (int base = 0; base < ITERS; base += 16) {
+            v4 r[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int it = base + k;
+                const size_t row = group * ROWS + (it / IPR) * RPI + lane / LPR;
+                r[k] = __builtin_nontemporal_load((const v4*)(x + row * n + t0 + (size_t)(it % IPR) * 256 + (lane % LPR) * 4));
+            }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int it = base + k;
+                const size_t row = group * ROWS + (it / IPR) * RPI + lane / LPR;
+                __builtin_nontemporal_store(r[k], (v4*)(y + row * n + t0 + (size_t)(it % IPR) * 256 + (lane % LPR) * 4));
+            }
+        }
+    }
+}
+
 int main(int argc, char** argv) {
     const size_t total = (size_t)1 << 28;
     void *a, *b; CK(hipMalloc(&a, total * 4 + (1 << 20))); CK(hipMalloc(&b, total * 4 + (1 << 20))); CK(hipMemset(a, 1, total * 4));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const int lds = argc > 1 ? atoi(argv[1]) : 30000;  // unused LDS: two one-wave workgroups per CU, as the batch IIR runs
-    const size_t lens[] = {3840, 4096, 4224, 5120, 8192, 16384};
+    const size_t lens[] = {3840, 4096, 4224, 5120, 9984, 16384};
     for (size_t n : lens) {
         const size_t rows = total / n / 64 * 64, groups = rows / 64, chunk = (groups + 7) / 8;
         const double bytes = 2.0 * rows * n * 4;
@@ -88,6 +116,11 @@ int main(int argc, char** argv) {
             run(delay == 0 ? "pipelined tiles, no delay" : (delay == 2 ? "pipelined tiles, 2 x s_sleep 16" : "pipelined tiles, 4 x s_sleep 16"),
                 [&]{ hipLaunchKernelGGL((copy_rows_pipelined<0>), dim3(8 * chunk), dim3(64), lds, 0, A, B, n, chunk, groups, delay); });
         run("pipelined tiles, launch-order groups", [&]{ hipLaunchKernelGGL((copy_rows_pipelined<1>), dim3(8 * chunk), dim3(64), lds, 0, A, B, n, chunk, groups, 2); });
+        {
+            const size_t g32 = rows / 32, c32 = (g32 + 7) / 8, g16 = rows / 16, c16 = (g16 + 7) / 8;
+            run("32 rows x 1 KB per wave", [&]{ hipLaunchKernelGGL((copy_rows_few<256, 32>), dim3(8 * c32), dim3(64), lds, 0, A, B, n, c32, g32); });
+            run("16 rows x 2 KB per wave", [&]{ hipLaunchKernelGGL((copy_rows_few<512, 16>), dim3(8 * c16), dim3(64), lds, 0, A, B, n, c16, g16); });
+        }
         CK(hipGetLastError());
     }
     return 0;
