@@ -487,7 +487,7 @@ static int convolve_impl(const char *who, const float *x, float *y, size_t chann
                                                                    // (long channels: the wave kernel at hop 3840 runs 1.6 ms on 1,024 x 2^20 at any
                                                                    // of these lengths, the direct kernel 1.60 at 31 taps and 1.93 at 63)
     const bool partitioned = ntaps > kSegmentTaps + 1 && !history && os_wanted;
-    // (one-shot calls on several channels of 2,305 ... 4,096 samples: 4096-point blocks, because launch_os then runs the channels
+    // (one-shot calls on several channels of 1,536 ... 4,096 samples: 4096-point blocks, because launch_os then runs the channels
     // as one signal -- 87,381 x 3,072 samples, 511 taps: 0.46 of HBM on two 2048-point blocks per channel, 0.58 that way)
     const bool as_one_signal = !history && channels >= 2 && n >= 1536 && n <= 4096 && ntaps <= 2049 && !getenv("DSP_GPU_FIR_NO_FLATTEN");
     const int os_log2n = as_one_signal ? 12 : os_block_log2n(ntaps, n, history != nullptr && position != 0);
