@@ -4,6 +4,8 @@
 //                                         the type every in-repo caller of the reference uses (coefficients.h:88-104)
 //   float / double samples, REF arithmetic  DSP_GPU_IIR_BATCH_REF: coefficients.h:106-130 / 172-182 operation for operation
 // Alignment is a kernel argument here (one instantiation per order instead of two): these are the widening routes.
+#include <algorithm>
+
 #include "iir_batch_core.h"
 
 namespace dspgpu {
@@ -51,10 +53,64 @@ int launch_iir_batch_ref_f64(const double *x, double *y, size_t channels, size_t
     return launch_any<double, iirb::IIR_ARITH_REF>(x, y, channels, n, co, state, pc, s);
 }
 
-// The block-parallel scan stages its zero-state outputs as fp32 rows (iir_kernels.hip); a double-sample form of it is
-// not built: AUTO runs double samples one lane per channel.
-int launch_iir_scan_f64(const double *, double *, size_t, size_t, const IirCoef &, double *, hipStream_t) {
-    return fail(DSP_GPU_EUNSUPPORTED, "IIR scan: double samples run in DSP_GPU_IIR_BATCH (AUTO picks it)");
+// SCAN for double samples: sharded in TIME on the one-lane-per-channel kernel.  (The block-parallel scan of iir_kernels.hip
+// stages its zero-state outputs as fp32 rows; a double form of it is not built.)  The reference's own callers filter ONE
+// SampleBuffer<double> (eval/recursive_filters/main.cpp:35): one lane walking a million samples takes 67 ms -- slower than the
+// reference's loop on a CPU core.  A stable filter forgets its state: after W = dsp_gpu_iir_settle samples the response to ANY
+// state has decayed below 2^-44 of it (iir_kernels.hip, iir_settle_samples), so every channel is cut into segments of L samples,
+//   1. the W samples in front of every segment are copied to a scratch matrix [segments][W] and run from a zero state, which
+//      leaves in state[g] the filter's state at segment g's first sample, exact to 2^-44 of its size (segments that begin a
+//      channel take the caller's state instead),
+//   2. the kernel runs over the [channels * segments][L] view of x and y, one lane per segment, from those states,
+//   3. the last segment of every channel hands the caller's state back; a single channel's remainder (n not a multiple of L)
+//      runs after it from that state.
+// W / L more arithmetic and reads (L >= 4 W), all in the reference's double arithmetic; 1 x 2^20 samples: 67 ms -> 0.09 ms, 1 x 2^27: 0.44 ms = 0.61 of HBM
+// (scripts/iir_f64_long.py).
+// EUNSUPPORTED (AUTO then runs one lane per channel): filters that do not settle within 8,192 samples, several channels
+// whose length has no suitable divisor, signals of fewer than two segments.
+int launch_iir_scan_f64(const double *x, double *y, size_t channels, size_t n, const IirCoef &co, double *state, hipStream_t s) {
+    size_t W = 0;
+    if (iir_settle_samples(co, &W) != DSP_GPU_OK || W > 8192)
+        return fail(DSP_GPU_EUNSUPPORTED, "IIR scan (double samples): the filter does not settle within 8,192 samples; use DSP_GPU_IIR_BATCH");
+    W = std::max<size_t>((W + 63) / 64 * 64, 64);
+    // about 32,768 lanes (two one-wave workgroups per CU), segments of at least 4 W samples, whole 512-byte rows
+    size_t L = std::max<size_t>(4 * W, (channels * n + 32767) / 32768);
+    L = (L + 63) / 64 * 64;
+    {  // the kernel walks rows of a power-of-two length fastest (profiles/r03_iir_batch_row_lengths.txt)
+        size_t p2 = 64;
+        while (p2 < L) p2 *= 2;
+        if (p2 <= 8192) L = p2;
+    }
+    if (channels > 1) {  // the view [channels * S][L] needs n = S * L
+        size_t found = 0;
+        for (size_t cand = L; cand <= 2 * L && cand <= n; cand += 64)
+            if (n % cand == 0) { found = cand; break; }
+        if (!found) return fail(DSP_GPU_EUNSUPPORTED, "IIR scan (double samples): no segment length divides %zu samples; use DSP_GPU_IIR_BATCH", n);
+        L = found;
+    }
+    const size_t S = n / L, tail = n - S * L;
+    if (S < 2) return fail(DSP_GPU_EUNSUPPORTED, "IIR scan (double samples): %zu samples are fewer than two segments; use DSP_GPU_IIR_BATCH", n);
+    const size_t G = channels * S;
+    const size_t sp = static_cast<size_t>(co.poles), row = 2 * sp * sizeof(double);
+    void *warm_v = nullptr, *st_v = nullptr;
+    if (int rc = workspace(WS_SCRATCH_A, G * W * sizeof(double), &warm_v, s)) return rc;
+    if (int rc = workspace(WS_SCRATCH_B, G * row, &st_v, s)) return rc;
+    double *warm = static_cast<double *>(warm_v), *st = static_cast<double *>(st_v);
+    // 1. (segment g begins at x + g L for every g, channels being n = S L apart; a channel's first segment gets the previous
+    //     channel's tail here and the caller's state below)
+    DSPGPU_HIP(hipMemcpy2DAsync(warm + W, W * sizeof(double), x + L - W, L * sizeof(double), W * sizeof(double), G - 1,
+                                hipMemcpyDeviceToDevice, s));
+    DSPGPU_HIP(hipMemsetAsync(st, 0, G * row, s));
+    if (int rc = launch_iir_batch_f64(warm + W, warm + W, G - 1, W, co, st + 2 * sp, nullptr, s)) return rc;
+    if (state) DSPGPU_HIP(hipMemcpy2DAsync(st, S * row, state, row, row, channels, hipMemcpyDeviceToDevice, s));
+    else DSPGPU_HIP(hipMemset2DAsync(st, S * row, 0, row, channels, s));
+    // 2.
+    if (int rc = launch_iir_batch_f64(x, y, G, L, co, st, nullptr, s)) return rc;
+    // 3.
+    if (tail)  // (channels == 1)
+        if (int rc = launch_iir_batch_f64(x + S * L, y + S * L, 1, tail, co, st + (G - 1) * 2 * sp, nullptr, s)) return rc;
+    if (state) DSPGPU_HIP(hipMemcpy2DAsync(state, row, st + (S - 1) * 2 * sp, S * row, row, channels, hipMemcpyDeviceToDevice, s));
+    return DSP_GPU_OK;
 }
 
 }  // namespace dspgpu

@@ -196,8 +196,11 @@ int dsp_gpu_moving_average_f64(const double *x, double *y, size_t channels, size
  * up to 8 poles (AUTO runs longer sections in BATCH).  Channel-major x[ch][n], y[ch][n].
  * Arithmetic and history are double, as in the reference (coefficients.h:9-12); samples are fp32
  * (dsp_gpu_iir) or double (dsp_gpu_iir_f64: SampleBuffer<double>, the type every in-repo caller of the reference
- * filters -- eval/recursive_filters/main.cpp:35; one lane per channel only: SCAN is DSP_GPU_EUNSUPPORTED there and
- * AUTO runs BATCH).  DSP_GPU_IIR_BATCH_REF reproduces the reference bit for bit (see the mode's comment).
+ * filters -- eval/recursive_filters/main.cpp:35.  SCAN on double samples is the one-lane kernel sharded in TIME: every
+ * channel cut into segments that start from states computed over dsp_gpu_iir_settle samples of warm-up, exact to
+ * 2^-44 of the state -- one channel of 2^20 doubles 67 ms -> 0.09 ms; DSP_GPU_EUNSUPPORTED for filters that do not
+ * settle within 8,192 samples and for several channels whose length no segment length divides, AUTO then runs BATCH).
+ * DSP_GPU_IIR_BATCH_REF reproduces the reference bit for bit (see the mode's comment).
  * `state` (may be NULL = start from rest, nothing written back) is [ch][2*poles] DOUBLES,
  * {x[t-1..t-poles], v[t-1..t-poles]} per channel, read before and written after the call:
  * it is the reference's x[]/y[] history (coefficients.h:11-12) made explicit so a long

@@ -188,15 +188,45 @@ def test_filter_bank_reference_arithmetic(ops, dev, orc, f64):
         assert np.array_equal(ops.iir_multi(x, A, B, c0, d0, mode="batch_ref", f64=f64), want)  # host route
 
 
-def test_double_samples_scan_is_refused_and_auto_runs_batch(ops, dev, orc):
+def test_double_samples_scan_is_sharded_in_time(ops, dev, orc):
+    """SCAN on double samples (what AUTO takes for a few long channels): every channel cut into segments that start from
+    states computed over dsp_gpu_iir_settle samples of warm-up (iir_batch_ext.hip) -- against the oracle's double recursion
+    and against one lane per channel, with and without a carried state, single channels with a remainder, several channels
+    with a dividing segment length; what cannot be sharded is refused and AUTO runs it one lane per channel."""
     import torch
     from dsp_amd import capi
+    rng = np.random.default_rng(11)
+    for fc, poles in ((0.1, 4), (0.25, 2), (0.05, 4)):
+        a, b = orc.chebyshev(fc, poles)
+        for channels, n in ((1, 100000), (1, 65536 + 777), (3, 1 << 16), (5, 30720)):
+            x = rng.standard_normal((channels, n))
+            xd = torch.from_numpy(x).to(dev)
+            want = orc.iir(x, a, b)
+            got = ops.iir_f64(xd, a, b, mode="scan").cpu().numpy()
+            assert rel_l2(got, want) <= F64_FAST, (fc, poles, channels, n)
+            assert rel_l2(got, ops.iir_f64(xd, a, b, mode="batch").cpu().numpy()) <= 1e-12
+            assert rel_l2(ops.iir_f64(xd, a, b, mode="auto").cpu().numpy(), want) <= F64_FAST
+            # two halves with the state carried = the whole
+            st = torch.zeros(channels, 2 * poles, dtype=torch.float64, device=dev)
+            h = (n // 2) // 64 * 64
+            y0 = ops.iir_f64(xd[:, :h].contiguous(), a, b, state=st, mode="scan")
+            st_b = st.clone()
+            y1 = ops.iir_f64(xd[:, h:].contiguous(), a, b, state=st, mode="auto")
+            assert rel_l2(torch.cat([y0, y1], dim=1).cpu().numpy(), want) <= F64_FAST, (fc, poles, channels, n)
+            # the state handed back is the one a single lane hands back
+            st_c = torch.zeros_like(st)
+            ops.iir_f64(xd[:, :h].contiguous(), a, b, state=st_c, mode="batch")
+            assert float((st_b - st_c).abs().max()) <= 1e-11 * max(float(st_c.abs().max()), 1.0)
     a, b = orc.chebyshev(0.1, 4)
-    x = torch.zeros(4, 5000, dtype=torch.float64, device=dev)
+    x = torch.zeros(4, 5000, dtype=torch.float64, device=dev)  # no multiple of 64 between 1,024 and 2,048 divides 5,000
     with pytest.raises(capi.DspGpuError) as e:
         ops.iir_f64(x, a, b, mode="scan")
     assert e.value.code == capi.EUNSUPPORTED
     ops.iir_f64(x, a, b, mode="auto")
+    with pytest.raises(capi.DspGpuError) as e:  # a filter that does not settle within 8,192 samples
+        a2, b2 = orc.chebyshev(0.001, 4)
+        ops.iir_f64(torch.zeros(1, 1 << 20, dtype=torch.float64, device=dev), a2, b2, mode="scan")
+    assert e.value.code == capi.EUNSUPPORTED
 
 
 def test_full_size_double_batch_properties(ops, dev, orc):
