@@ -564,7 +564,7 @@ void store_mat(std::vector<double> &table, size_t slot, const Mat &m, int P, boo
 // the recursion can grow in the output
 double feedback_noise_gain(const IirCoef &co) {
     const int P = co.poles;
-    double h[9] = {0};
+    double h[21] = {0};  // (poles <= 20: dsp_gpu_iir_settle takes every order the library filters, not only the scan's eight)
     double total = 1.0;
     h[0] = 1.0;  // h[i] = response i steps ago
     for (int k = 1; k < (1 << 22); ++k) {

@@ -56,6 +56,31 @@ def test_settle_length_matches_the_decay(golden):
         ops.iir_settle(np.array([1.0, 0.0, 0.0]), np.array([0.0, 2.0 * np.cos(0.3), -1.0]))
 
 
+def test_settle_takes_every_order_the_library_filters():
+    """Orders above the scan's eight poles too (Coefficients<2..20>, recursive_filters.h:30-31): round 3 found the noise-gain
+    recursion behind dsp_gpu_iir_settle keeping its history in an array of nine (a stack overrun from ten poles on, a crash at
+    sixteen).  Every order answers with a whole number of 64-sample blocks or a clean refusal, and the answer is a decay."""
+    from dsp_amd import capi, design, ops
+    answered = 0
+    for poles in range(2, 21, 2):
+        for fc in (0.1, 0.25, 0.4):
+            a, b = design.low_pass(fc, poles)
+            try:
+                w = ops.iir_settle(a, b)
+            except capi.DspGpuError as e:
+                assert e.code == capi.EUNSUPPORTED, (poles, fc)
+                continue
+            answered += 1
+            assert w % 64 == 0 and 64 <= w <= 64 * 3840, (poles, fc, w)
+            v = np.zeros(poles)
+            v[0] = 1.0
+            for t in range(w + 4):  # zero-input run from a unit state, in extended precision where numpy has it
+                nv = float(np.dot(np.asarray(b[1:], dtype=np.longdouble), v.astype(np.longdouble)))
+                v = np.concatenate(([nv], v[:-1]))
+            assert np.abs(v).max() <= 2.0 ** -30, (poles, fc, w)
+    assert answered >= 20
+
+
 def _gloo_worker(rank, world, rdzv, outdir):
     import torch
     import torch.distributed as dist
