@@ -21,6 +21,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
@@ -187,8 +188,31 @@ void everything() {
 }
 }  // namespace
 
+// dsp_gpu_iir_settle is host arithmetic on up to 20 poles (a nine-element history array overran from ten poles on until late
+// round 3): sections of every order, stable (a pole at radius rho repeated) and not, answered or refused without touching
+// memory that is not theirs.
+void settle_every_order() {
+    for (int poles = 1; poles <= 20; ++poles) {
+        for (double rho : {0.5, 0.9, 0.99, 1.01}) {
+            // (1 - rho z^-1)^poles expanded: b[i] = -(-rho)^i C(poles, i), feedback ADDED
+            std::vector<double> a(poles + 1, 0.0), b(poles + 1, 0.0);
+            a[0] = 1.0;
+            double c = 1.0;
+            for (int i = 1; i <= poles; ++i) {
+                c = c * (poles - i + 1) / i;
+                b[i] = -std::pow(-rho, i) * c;
+            }
+            size_t w = 0;
+            const int rc = dsp_gpu_iir_settle(a.data(), b.data(), poles, &w);
+            EXPECT(rc == 0 || rc == DSP_GPU_EUNSUPPORTED, "iir_settle answers or refuses");
+            if (rc == 0) EXPECT(w % 32 == 0 && w > 0, "iir_settle: whole blocks");
+        }
+    }
+}
+
 int main(int argc, char **argv) {
     if (argc > 1) g_rounds = std::max(1, std::atoi(argv[1]));
+    settle_every_order();
     everything();
     EXPECT(dsp_gpu_shutdown() == 0, "shutdown");
     everything();  // tables and pipelines come back after a shutdown
