@@ -712,6 +712,11 @@ int iir_impl(const char *who, const T *x, T *y, size_t channels, size_t n, const
             return rc;
         } else {
             if (mode == DSP_GPU_IIR_BATCH_REF) return launch_iir_batch_ref(dx, dy, count, n, co, dstate, nullptr, s);
+            if (auto_mode && mode == DSP_GPU_IIR_BATCH && poles > 8 && dx != dy && ((count < 24576 && n >= 2048) || n >= 16384)) {
+                // more poles than the scan has a kernel for, few long channels: the one-lane kernel sharded in time
+                const int rc = launch_iir_sharded(dx, dy, count, n, co, dstate, s);
+                if (rc != DSP_GPU_EUNSUPPORTED) return rc;
+            }
             int rc = mode == DSP_GPU_IIR_SCAN ? launch_iir_scan(dx, dy, count, n, co, dstate, s)
                                               : launch_iir_batch(dx, dy, count, n, co, dstate, nullptr, s);
             if (rc == DSP_GPU_EUNSUPPORTED && auto_mode && mode == DSP_GPU_IIR_SCAN)  // ill-conditioned for the scan

@@ -177,6 +177,7 @@ int launch_iir_batch_ref_f64(const double *x, double *y, size_t channels, size_t
                              const IirPerChannel *per_channel, hipStream_t s);
 int launch_iir_scan_f64(const double *x, double *y, size_t channels, size_t n, const IirCoef &co, double *state, hipStream_t s);
 int iir_settle_samples(const IirCoef &co, size_t *samples);
+int launch_iir_sharded(const float *x, float *y, size_t channels, size_t n, const IirCoef &co, double *state, hipStream_t s);
 int launch_iir_scan(const float *x, float *y, size_t channels, size_t n, const IirCoef &co, double *state,
                     hipStream_t s);
 // A band-pass (kind 0) / band-reject (kind 1) BiQuad redesigned at every sample from fc[ch * fc_stride + t]
