@@ -188,8 +188,8 @@ void everything() {
 }
 }  // namespace
 
-// dsp_gpu_iir_settle is host arithmetic on up to 20 poles (a nine-element history array overran from ten poles on until late
-// round 3): sections of every order, stable (a pole at radius rho repeated) and not, answered or refused without touching
+// dsp_gpu_iir_settle takes up to 20 poles (its arithmetic lives beside the scan kernels and is stubbed in this build: this walks the
+// entry point's own argument handling; the arithmetic is walked by tests/test_iir_time_sharded.py): sections of every order, stable (a pole at radius rho repeated) and not, answered or refused without touching
 // memory that is not theirs.
 void settle_every_order() {
     for (int poles = 1; poles <= 20; ++poles) {

@@ -134,6 +134,7 @@ int launch_iir_batch_ref(const float *x, float *y, size_t c, size_t n, const Iir
 int launch_iir_batch_ref_f64(const double *x, double *y, size_t c, size_t n, const IirCoef &co, double *st, const IirPerChannel *pc, hipStream_t) { return iir_any(x, y, c, n, co, st, pc); }
 int launch_iir_scan(const float *x, float *y, size_t c, size_t n, const IirCoef &co, double *st, hipStream_t) { return iir_any(x, y, c, n, co, st, nullptr); }
 int launch_iir_scan_f64(const double *x, double *y, size_t c, size_t n, const IirCoef &co, double *st, hipStream_t) { return iir_any(x, y, c, n, co, st, nullptr); }
+int launch_iir_sharded(const float *x, float *y, size_t c, size_t n, const IirCoef &co, double *st, hipStream_t) { return iir_any(x, y, c, n, co, st, nullptr); }
 int iir_settle_samples(const IirCoef &, size_t *samples) { *samples = 256; return DSP_GPU_OK; }
 int launch_biquad_swept(const float *x, const float *fc, float *y, size_t channels, size_t n, size_t fc_stride, int, double, double *state,
                         hipStream_t) {
