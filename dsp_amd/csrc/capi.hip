@@ -705,6 +705,11 @@ int iir_impl(const char *who, const T *x, T *y, size_t channels, size_t n, const
     auto run = [=](const T *dx, T *dy, size_t count, double *dstate) {
         if constexpr (kF64) {
             if (mode == DSP_GPU_IIR_BATCH_REF) return launch_iir_batch_ref_f64(dx, dy, count, n, co, dstate, nullptr, s);
+            if (auto_mode && mode == DSP_GPU_IIR_BATCH && poles > 8 && dx != dy && ((count < 24576 && n >= 2048) || n >= 16384)) {
+                // (AUTO asks for the scan up to eight poles only, the fp32 kernel's limit: the time-sharded form has none)
+                const int rc = launch_iir_scan_f64(dx, dy, count, n, co, dstate, s);
+                if (rc != DSP_GPU_EUNSUPPORTED) return rc;
+            }
             int rc = mode == DSP_GPU_IIR_SCAN ? launch_iir_scan_f64(dx, dy, count, n, co, dstate, s)
                                               : launch_iir_batch_f64(dx, dy, count, n, co, dstate, nullptr, s);
             if (rc == DSP_GPU_EUNSUPPORTED && auto_mode && mode == DSP_GPU_IIR_SCAN)

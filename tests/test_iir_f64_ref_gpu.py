@@ -217,8 +217,15 @@ def test_double_samples_scan_is_sharded_in_time(ops, dev, orc):
             st_c = torch.zeros_like(st)
             ops.iir_f64(xd[:, :h].contiguous(), a, b, state=st_c, mode="batch")
             assert float((st_b - st_c).abs().max()) <= 1e-11 * max(float(st_c.abs().max()), 1.0)
+    # more poles than AUTO asks the scan for with fp32 samples: doubles are sharded at every order
+    a, b = orc.chebyshev(0.25, 12)
+    x = rng.standard_normal((1, 200000))
+    xd = torch.from_numpy(x).to(dev)
+    got = ops.iir_f64(xd, a, b, mode="auto").cpu().numpy()
+    assert rel_l2(got, ops.iir_f64(xd, a, b, mode="batch").cpu().numpy()) <= 1e-11
+    assert rel_l2(got, orc.iir(x, a, b)) <= 1e-9  # (a 12-pole direct form: the one-lane run is no closer)
     a, b = orc.chebyshev(0.1, 4)
-    x = torch.zeros(4, 5000, dtype=torch.float64, device=dev)  # no multiple of 64 between 1,024 and 2,048 divides 5,000
+    x = torch.zeros(4, 5000, dtype=torch.float64, device=dev)  # no multiple of 64 between 2,048 and 4,096 divides 5,000
     with pytest.raises(capi.DspGpuError) as e:
         ops.iir_f64(x, a, b, mode="scan")
     assert e.value.code == capi.EUNSUPPORTED
