@@ -85,11 +85,21 @@ int time_sharded(const T *x, T *y, size_t channels, size_t n, const IirCoef &co,
         while (p2 < L) p2 *= 2;
         if (p2 <= 8192) L = p2;
     }
-    if (channels > 1) {  // the view [channels * S][L] needs n = S * L
+    if (channels > 1) {  // the view [channels * S][L] needs n = S * L: whole 512-byte rows if there are such, else 16-byte ones
         size_t found = 0;
-        for (size_t cand = L; cand <= 2 * L && cand <= n; cand += 64)
-            if (n % cand == 0) { found = cand; break; }
-        if (!found) return fail(DSP_GPU_EUNSUPPORTED, "IIR in time shards: no segment length divides %zu samples; use DSP_GPU_IIR_BATCH", n);
+        for (size_t cand = L; cand <= 2 * L && cand <= n && !found; cand += 64)
+            if (n % cand == 0) found = cand;
+        constexpr size_t kGroup = 16 / sizeof(T);
+        for (size_t cand = (4 * W + kGroup - 1) / kGroup * kGroup; cand <= 4 * L && cand <= n && !found; cand += kGroup)
+            if (n % cand == 0) found = cand;
+        if (!found) {
+            // no such length (an odd or near-prime n): a few channels go one after the other, each with its remainder
+            if (channels > 64) return fail(DSP_GPU_EUNSUPPORTED, "IIR in time shards: no segment length divides %zu samples; use DSP_GPU_IIR_BATCH", n);
+            for (size_t c = 0; c < channels; ++c)
+                if (int rc = time_sharded<T>(x + c * n, y + c * n, 1, n, co, state ? state + c * 2 * static_cast<size_t>(co.poles) : nullptr, s, batch))
+                    return rc;
+            return DSP_GPU_OK;
+        }
         L = found;
     }
     const size_t S = n / L, tail = n - S * L;

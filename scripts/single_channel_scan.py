@@ -23,14 +23,16 @@ def t(fn, reps=3):
 
 
 h511, h31 = design.sinc(0.1, 511), design.sinc(0.1, 31)
-for log2n in (12, 16, 20, 24):
-    n = 1 << log2n
-    x32 = torch.randn(1, n, device=dev)
+shapes = [(1, 1 << 12), (1, 1 << 16), (1, 1 << 20), (1, 1 << 24)]
+if len(sys.argv) > 1:
+    shapes = [tuple(int(v) for v in a.split("x")) for a in sys.argv[1:]]
+for ch, n in shapes:
+    x32 = torch.randn(ch, n, device=dev)
     x64 = x32.double()
-    c32 = torch.view_as_complex(torch.randn(1, n, 2, device=dev))
+    c32 = torch.view_as_complex(torch.randn(ch, 1 << (n.bit_length() - 1), 2, device=dev))
     c64 = c32.to(torch.complex128)
-    fc = torch.full((1, n), 0.1, device=dev)
-    rows = [("fft0", lambda: ops.fft0(c32)), ("fft0_f64", lambda: ops.fft0_f64(c64)), ("fft real", lambda: ops.fft(x32, n)),
+    fc = torch.full((ch, n), 0.1, device=dev)
+    rows = [("fft0", lambda: ops.fft0(c32)), ("fft0_f64", lambda: ops.fft0_f64(c64)), ("fft real", lambda: ops.fft(x32, 1 << (n - 1).bit_length())),
             ("conv31", lambda: ops.convolve(x32, h31)), ("conv511", lambda: ops.convolve(x32, h511)),
             ("conv31_f64", lambda: ops.convolve_f64(x64, h31)), ("conv511_f64", lambda: ops.convolve_f64(x64, h511)),
             ("mavg", lambda: ops.moving_average(x32, 511)), ("mavg_f64", lambda: ops.moving_average_f64(x64, 511))]
@@ -39,7 +41,7 @@ for log2n in (12, 16, 20, 24):
         rows.append((f"iir{poles}", lambda a=a, b=b: ops.iir(x32, a, b)))
         rows.append((f"iir{poles}_f64", lambda a=a, b=b: ops.iir_f64(x64, a, b)))
     rows.append(("swept", lambda: ops.biquad_swept(x32, fc, 0.01)))
-    line = f"n=2^{log2n}:"
+    line = f"{ch} x {n}:"
     for name, fn in rows:
         try:
             ms = t(fn)

@@ -224,8 +224,19 @@ def test_double_samples_scan_is_sharded_in_time(ops, dev, orc):
     got = ops.iir_f64(xd, a, b, mode="auto").cpu().numpy()
     assert rel_l2(got, ops.iir_f64(xd, a, b, mode="batch").cpu().numpy()) <= 1e-11
     assert rel_l2(got, orc.iir(x, a, b)) <= 1e-9  # (a 12-pole direct form: the one-lane run is no closer)
+    # channel lengths without a 512-byte-row divisor (16-byte rows then), odd lengths (a few channels: one after the other, each
+    # with its remainder), too short for two segments (refused; AUTO runs one lane per channel)
     a, b = orc.chebyshev(0.1, 4)
-    x = torch.zeros(4, 5000, dtype=torch.float64, device=dev)  # no multiple of 64 between 2,048 and 4,096 divides 5,000
+    for channels, n in ((4, 30000), (3, 100001), (2, 65535)):
+        x = rng.standard_normal((channels, n))
+        xd = torch.from_numpy(x).to(dev)
+        st = torch.zeros(channels, 8, dtype=torch.float64, device=dev)
+        got = ops.iir_f64(xd, a, b, state=st, mode="scan").cpu().numpy()
+        assert rel_l2(got, orc.iir(x, a, b)) <= F64_FAST, (channels, n)
+        st_seq = torch.zeros_like(st)
+        ops.iir_f64(xd, a, b, state=st_seq, mode="batch")
+        assert float((st - st_seq).abs().max()) <= 1e-11 * max(float(st_seq.abs().max()), 1.0), (channels, n)
+    x = torch.zeros(4, 3000, dtype=torch.float64, device=dev)
     with pytest.raises(capi.DspGpuError) as e:
         ops.iir_f64(x, a, b, mode="scan")
     assert e.value.code == capi.EUNSUPPORTED
