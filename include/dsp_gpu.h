@@ -199,7 +199,8 @@ int dsp_gpu_moving_average_f64(const double *x, double *y, size_t channels, size
  * filters -- eval/recursive_filters/main.cpp:35.  SCAN on double samples is the one-lane kernel sharded in TIME: every
  * channel cut into segments that start from states computed over twice dsp_gpu_iir_settle samples of warm-up, exact to
  * 2^-88 of the state -- one channel of 2^20 doubles 67 ms -> 0.16 ms; DSP_GPU_EUNSUPPORTED for filters that do not
- * settle within 8,192 samples and for several channels whose length no segment length divides, AUTO then runs BATCH).
+ * settle within 8,192 samples, channels of fewer than two segments, and more than 64 channels whose length no segment
+ * length divides; AUTO then runs BATCH.  AUTO also takes this form for fp32 sections of more than eight poles).
  * DSP_GPU_IIR_BATCH_REF reproduces the reference bit for bit (see the mode's comment).
  * `state` (may be NULL = start from rest, nothing written back) is [ch][2*poles] DOUBLES,
  * {x[t-1..t-poles], v[t-1..t-poles]} per channel, read before and written after the call:
