@@ -19,7 +19,9 @@
 // 64-sample rows; 3.68 ms with swept_cos.h; 3.25 ms with 32-sample rows (two waves per SIMD); 3.04 ms with the four
 // cosines of a float4 evaluated together and the sine kernel skipped per wave; 2.93 ms = 367 GSamples/s, 4.4 TB/s with
 // a bounds-test-free path for full tiles.
+#include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 #include "common.h"
 #include "swept_cos.h"
@@ -404,8 +406,69 @@ int swept_dispatch(const float *x, const float *fc, float *y, size_t channels, s
 
 }  // namespace
 
+namespace {
+int swept_plain(const float *x, const float *fc, float *y, size_t channels, size_t n, size_t fc_stride, int kind,
+                double bandwidth, double *state, hipStream_t s);
+}
+
+// A few long voices (the wind generator is ONE, 60 s at 44.1 kHz: eval/signals/wind_generator.h:150-167): one lane per voice walks
+// 2^20 samples in 194 ms, slower than the reference's loop on a CPU core.  The section is redesigned at every sample, but its pole
+// radius R = 1 - 3 BW never changes (recursive_filters.h:165-209), so the response to any state decays like R^t whatever the sweep
+// does: the voice is sharded in TIME as the IIR is (iir_batch_ext.hip) -- segments of L samples, each started from the state that
+// W samples of warm-up from rest leave, W = 2 * 44 ln 2 / -ln R (2^-88: the factor two covers the non-normal growth of a section
+// tuned near 0 or 0.5).  Sweeps must run along with the samples: one voice, or every voice its own sweep (fc_stride == n).
 int launch_biquad_swept(const float *x, const float *fc, float *y, size_t channels, size_t n, size_t fc_stride, int kind,
                         double bandwidth, double *state, hipStream_t s) {
+    const double R = 1.0 - 3.0 * bandwidth;
+    const bool shardable = channels <= 4096 && (channels == 1 || fc_stride == n) && R > 0.0 && R < 0.99999 && !getenv("DSP_GPU_SWEPT_NO_SHARDS");
+    if (shardable) {
+        size_t W = static_cast<size_t>(std::ceil(2.0 * 44.0 * 0.6931471805599453 / -std::log(R)));
+        W = std::max<size_t>((W + 127) / 128 * 128, 128);
+        size_t L = std::max<size_t>(4 * W, (channels * n + 32767) / 32768);
+        L = (L + 127) / 128 * 128;
+        {
+            size_t p2 = 128;
+            while (p2 < L) p2 *= 2;
+            if (p2 <= 8192) L = p2;
+        }
+        bool ok = W <= 65536 && n >= 2 * L;
+        if (ok && channels > 1) {  // the view [channels * S][L] needs n = S * L
+            size_t found = 0;
+            for (size_t cand = L; cand <= 2 * L && cand <= n && !found; cand += 128)
+                if (n % cand == 0) found = cand;
+            for (size_t cand = 4 * W; cand <= 4 * L && cand <= n && !found; cand += 4)
+                if (n % cand == 0) found = cand;
+            ok = found != 0;
+            if (ok) L = found;
+        }
+        if (ok) {
+            const size_t S = n / L, tail = n - S * L, G = channels * S;
+            void *p = nullptr;
+            if (int rc = workspace(WS_SCRATCH_B, 2 * G * W * sizeof(float) + G * 4 * sizeof(double), &p, s)) return rc;
+            double *st = static_cast<double *>(p);  // (first: 8-byte aligned whatever G and W are)
+            float *xw = reinterpret_cast<float *>(st + G * 4), *fw = xw + G * W;
+            const size_t row = 4 * sizeof(double);
+            // the W samples (and sweep values) in front of every segment but the first; a voice's first segment gets the previous
+            // voice's tail here and the caller's state below
+            DSPGPU_HIP(hipMemcpy2DAsync(xw + W, W * sizeof(float), x + L - W, L * sizeof(float), W * sizeof(float), G - 1, hipMemcpyDeviceToDevice, s));
+            DSPGPU_HIP(hipMemcpy2DAsync(fw + W, W * sizeof(float), fc + L - W, L * sizeof(float), W * sizeof(float), G - 1, hipMemcpyDeviceToDevice, s));
+            DSPGPU_HIP(hipMemsetAsync(st, 0, G * row, s));
+            if (int rc = swept_plain(xw + W, fw + W, xw + W, G - 1, W, W, kind, bandwidth, st + 4, s)) return rc;
+            if (state) DSPGPU_HIP(hipMemcpy2DAsync(st, S * row, state, row, row, channels, hipMemcpyDeviceToDevice, s));
+            else DSPGPU_HIP(hipMemset2DAsync(st, S * row, 0, row, channels, s));
+            if (int rc = swept_plain(x, fc, y, G, L, L, kind, bandwidth, st, s)) return rc;
+            if (tail)  // (channels == 1)
+                if (int rc = swept_plain(x + S * L, fc + S * L, y + S * L, 1, tail, tail, kind, bandwidth, st + (G - 1) * 4, s)) return rc;
+            if (state) DSPGPU_HIP(hipMemcpy2DAsync(state, row, st + (S - 1) * 4, S * row, row, channels, hipMemcpyDeviceToDevice, s));
+            return DSP_GPU_OK;
+        }
+    }
+    return swept_plain(x, fc, y, channels, n, fc_stride, kind, bandwidth, state, s);
+}
+
+namespace {
+int swept_plain(const float *x, const float *fc, float *y, size_t channels, size_t n, size_t fc_stride, int kind,
+                double bandwidth, double *state, hipStream_t s) {
     const bool al = n % 4 == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0 && reinterpret_cast<uintptr_t>(y) % 16 == 0 &&
                     reinterpret_cast<uintptr_t>(fc) % 16 == 0;
     if (kind == 0)
@@ -416,5 +479,6 @@ int launch_biquad_swept(const float *x, const float *fc, float *y, size_t channe
                   : swept_dispatch<1, false>(x, fc, y, channels, n, fc_stride, bandwidth, state, s);
     return fail(DSP_GPU_EINVAL, "swept biquad: kind %d", kind);
 }
+}  // namespace
 
 }  // namespace dspgpu

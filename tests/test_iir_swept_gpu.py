@@ -254,3 +254,31 @@ def test_errors(ops, dev):
         ops.biquad_swept(x, fc, BW, state=torch.zeros(4, 3, dtype=torch.float64, device=dev))
     with pytest.raises(capi.DspGpuError):
         ops.biquad_swept(x, fc.cpu().numpy(), BW)                      # fc must live where x lives
+
+
+@pytest.mark.gpu
+def test_few_long_voices_are_sharded_in_time(dev, monkeypatch):
+    """One voice (the wind generator's shape) and a few voices with their own sweeps: segments started from states that a warm-up
+    of 2 * 44 ln 2 / -ln R samples leaves (iir_swept_kernels.hip) against one lane per voice (DSP_GPU_SWEPT_NO_SHARDS=1): outputs
+    to fp32 rounding, the state handed back, chunked == unchunked, a remainder, sweeps through the whole band."""
+    import torch
+    from dsp_amd import ops
+    g = torch.Generator(device=dev).manual_seed(5)
+    for channels, n, bw in ((1, 300000 + 77, 0.01), (1, 1 << 18, 60.0 / 44100.0), (3, 1 << 17, 0.02), (2, 200000, 0.005)):
+        x = torch.randn(channels, n, device=dev, generator=g)
+        t = torch.arange(n, device=dev, dtype=torch.float32) / n
+        fc = (0.02 + 0.45 * (0.5 + 0.5 * torch.sin(2 * np.pi * (3 + torch.arange(channels, device=dev)[:, None]) * t[None, :]))).contiguous()
+        for kind in ("bandpass", "bandreject"):
+            st = torch.zeros(channels, 4, dtype=torch.float64, device=dev)
+            h = (n // 2) // 128 * 128
+            y0 = ops.biquad_swept(x[:, :h].contiguous(), fc[:, :h].contiguous(), bw, kind=kind, state=st)
+            y1 = ops.biquad_swept(x[:, h:].contiguous(), fc[:, h:].contiguous(), bw, kind=kind, state=st)
+            whole = ops.biquad_swept(x, fc, bw, kind=kind)
+            monkeypatch.setenv("DSP_GPU_SWEPT_NO_SHARDS", "1")
+            st_seq = torch.zeros_like(st)
+            seq = ops.biquad_swept(x, fc, bw, kind=kind, state=st_seq)
+            monkeypatch.delenv("DSP_GPU_SWEPT_NO_SHARDS")
+            den = float(torch.linalg.vector_norm(seq.double()))
+            assert float(torch.linalg.vector_norm((whole - seq).double())) <= 2e-6 * den, (channels, n, bw, kind)
+            assert float(torch.linalg.vector_norm((torch.cat([y0, y1], dim=1) - seq).double())) <= 2e-6 * den, (channels, n, bw, kind)
+            assert float((st - st_seq).abs().max()) <= 1e-5 * max(float(st_seq.abs().max()), 1.0), (channels, n, bw, kind)
