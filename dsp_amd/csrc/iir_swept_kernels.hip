@@ -440,6 +440,12 @@ int launch_biquad_swept(const float *x, const float *fc, float *y, size_t channe
                 if (n % cand == 0) found = cand;
             ok = found != 0;
             if (ok) L = found;
+            if (!ok && channels <= 64) {  // an odd or near-prime length: the few voices one after the other, each with its remainder
+                for (size_t c = 0; c < channels; ++c)
+                    if (int rc = launch_biquad_swept(x + c * n, fc + c * n, y + c * n, 1, n, n, kind, bandwidth, state ? state + 4 * c : nullptr, s))
+                        return rc;
+                return DSP_GPU_OK;
+            }
         }
         if (ok) {
             const size_t S = n / L, tail = n - S * L, G = channels * S;

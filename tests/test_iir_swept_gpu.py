@@ -264,7 +264,7 @@ def test_few_long_voices_are_sharded_in_time(dev, monkeypatch):
     import torch
     from dsp_amd import ops
     g = torch.Generator(device=dev).manual_seed(5)
-    for channels, n, bw in ((1, 300000 + 77, 0.01), (1, 1 << 18, 60.0 / 44100.0), (3, 1 << 17, 0.02), (2, 200000, 0.005)):
+    for channels, n, bw in ((1, 300000 + 77, 0.01), (1, 1 << 18, 60.0 / 44100.0), (3, 1 << 17, 0.02), (2, 200000, 0.005), (2, 99999, 0.02)):
         x = torch.randn(channels, n, device=dev, generator=g)
         t = torch.arange(n, device=dev, dtype=torch.float32) / n
         fc = (0.02 + 0.45 * (0.5 + 0.5 * torch.sin(2 * np.pi * (3 + torch.arange(channels, device=dev)[:, None]) * t[None, :]))).contiguous()
