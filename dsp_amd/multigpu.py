@@ -39,7 +39,7 @@ def iir_time_sharded(x_local, a, b, c0: float = 1.0, d0: float = 0.0, *, rank: i
     (dsp_gpu_iir_settle: ||A^k|| <= 2^-44) the state no longer depends on where it started.  So
       1. every rank filters its segment from a zero state and keeps the end state Z_g = {last P inputs, last P outputs};
       2. the end states are all-gathered (2P doubles per channel and rank: the only exchange);
-      3. rank g > 0 re-runs its first `settle` outputs from Z_{g-1}, which is the true state there to double rounding.
+      3. rank g > 0 re-runs its first 2 * `settle` outputs from Z_{g-1}, which is the true state there to double rounding.
     Returns (y_local, final_state): final_state is the state after the LAST rank's last sample on every rank (what a
     following block would start from).  `state` (rank 0 only matters): the state before the first sample.
     x_local: [channels, n_local] or [n_local] fp32 on this rank's GPU, n_local >= settle.
@@ -69,7 +69,8 @@ def iir_time_sharded(x_local, a, b, c0: float = 1.0, d0: float = 0.0, *, rank: i
     states = gather_states(st)
     if rank > 0:
         head_state = states[rank - 1].clone()
-        w = min(int(settle), n_local)
+        w = min(2 * int(settle), n_local)  # twice the settle length: 2^-44 of the STATE can be 1e-5 of the OUTPUT of an ill-conditioned
+        # high-order direct form (iir_batch_ext.hip, where the same sharding runs inside one GPU)
         y[:, :w] = iir(x2[:, :w].contiguous(), a, b, c0, d0, state=head_state, mode=mode)
     final = states[world - 1]
     return (y if x_local.ndim > 1 else y[0]), final
